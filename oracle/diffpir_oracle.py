@@ -1,0 +1,336 @@
+"""Oracle: restatement of the DiffPIR restoration loop and its operators (torch-CPU fp32 / numpy).
+
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Follows (reference paths relative to /root/reference):
+  * driver schedule tables      main_ddpir.py:184-190 (float32), 274-286 (rhos/sigmas)
+  * diffusion tables            guided_diffusion/gaussian_diffusion.py:27-35, 133-151 (float64)
+  * timestep sequence           main_ddpir.py:327-335, 342-344, 451
+  * model_fn -> pred_xstart     utils/utils_model.py:202-258, gaussian_diffusion.py:232-333, 395-439
+  * FFT prox                    utils/utils_sisr.py:9-95
+  * masked prox                 main_ddpir.py:392-394
+  * cubic IBP prox + Resizer    main_ddpir.py:401-406, utils/utils_resizer.py:9-178
+  * re-noise                    main_ddpir.py:448-456
+  * init / output               main_ddpir.py:291-315, 470, 482; utils/utils_image.py:238-242
+  * PSNR                        utils/utils_image.py:601-610
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Callable, List, Optional
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import unet_oracle as uo
+
+
+# ------------------------------------------------------------------ schedules
+class DriverTables:
+    """main_ddpir.py:184-190 -- float32 tables, cumprod done by numpy on the float32 tensor."""
+
+    def __init__(self, beta_start=0.0001, beta_end=0.02, T=1000):
+        betas = torch.from_numpy(np.linspace(beta_start, beta_end, T, dtype=np.float32))
+        alphas = 1.0 - betas
+        ac = np.cumprod(alphas, axis=0)                      # torch tensor in, torch tensor out
+        ac = torch.as_tensor(ac)
+        self.T = T
+        self.betas = betas
+        self.alphas = alphas
+        self.alphas_cumprod = ac
+        self.sqrt_ac = torch.sqrt(ac)
+        self.sqrt_1m_ac = torch.sqrt(1.0 - ac)
+        self.reduced = torch.div(self.sqrt_1m_ac, self.sqrt_ac)   # sigma-bar
+
+
+class DiffusionTables:
+    """gaussian_diffusion.py:27-35,133-151 -- float64 linear schedule used inside p_mean_variance."""
+
+    def __init__(self, T=1000):
+        scale = 1000 / T
+        betas = np.linspace(scale * 0.0001, scale * 0.02, T, dtype=np.float64)
+        ac = np.cumprod(1.0 - betas, axis=0)
+        self.sqrt_recip_ac = np.sqrt(1.0 / ac)
+        self.sqrt_recipm1_ac = np.sqrt(1.0 / ac - 1)
+
+
+def find_nearest(array, value) -> int:
+    """utils_model.py:202-205."""
+    array = np.asarray(array)
+    return int(np.abs(array - value).argmin())
+
+
+def make_seq(T: int, iter_num: int, skip_type: str = "quad") -> List[int]:
+    """main_ddpir.py:327-335."""
+    skip = T // iter_num
+    if skip_type == "uniform":
+        seq = [i * skip for i in range(iter_num)]
+        if skip > 1:
+            seq.append(T - 1)
+    else:
+        s = np.sqrt(np.linspace(0, T ** 2, iter_num))
+        seq = [int(v) for v in list(s)]
+        seq[-1] = seq[-1] - 1
+    return seq
+
+
+@dataclass
+class LoopConfig:
+    """The YAML keys that reach the loop (configs/*.yaml; main_ddpir.py:138-158)."""
+    task: str = "deblur"                 # deblur | sr | inpaint
+    iter_num: int = 100
+    noise_level_img: float = 12.75 / 255.0   # already divided by 255 (main_ddpir.py:138)
+    lambda_: float = 7.0
+    zeta: float = 0.3
+    eta: float = 0.0
+    guidance_scale: float = 1.0
+    sf: int = 1
+    sr_mode: str = "blur"
+    inIter: int = 1
+    gamma: float = 0.01
+    skip_type: str = "quad"
+    T: int = 1000
+    beta_start: float = 0.0001
+    beta_end: float = 0.02
+
+    @property
+    def sigma(self):                     # main_ddpir.py:141
+        return max(0.001, self.noise_level_img)
+
+
+def step_tables(cfg: LoopConfig):
+    """Per-step scalars (SURVEY 8 a-S): list of dicts with t_i, t_im1, tau, is_last."""
+    dt = DriverTables(cfg.beta_start, cfg.beta_end, cfg.T)
+    T = cfg.T
+    # main_ddpir.py:274-286
+    sigmas = [dt.reduced[T - 1 - i] for i in range(T)]
+    sigma_ks = [dt.sqrt_1m_ac[i] / dt.sqrt_ac[i] for i in range(T)]
+    rhos = [cfg.lambda_ * (cfg.sigma ** 2) / (sigma_ks[i] ** 2) for i in range(T)]
+    rhos = torch.tensor(rhos)
+    sigmas = torch.tensor(sigmas)
+    seq = make_seq(T, cfg.iter_num, cfg.skip_type)
+    steps = []
+    for i in range(len(seq)):
+        curr_sigma = sigmas[seq[i]].cpu().numpy()
+        t_i = find_nearest(dt.reduced, curr_sigma)
+        last = seq[i] == seq[-1]
+        t_im1 = None if last else find_nearest(dt.reduced, sigmas[seq[i + 1]].cpu().numpy())
+        steps.append(dict(i=i, t_i=t_i, t_im1=t_im1, curr_sigma=curr_sigma, tau=rhos[t_i].float(), last=last))
+    return dt, steps
+
+
+# ------------------------------------------------------------------ denoiser plug
+def pred_xstart_from_eps(x, eps, t: int, dtab: DiffusionTables):
+    """gaussian_diffusion.py:328-333 + clamp :297: float64 table entries cast .float()."""
+    c1 = torch.tensor(dtab.sqrt_recip_ac[t]).float()
+    c2 = torch.tensor(dtab.sqrt_recipm1_ac[t]).float()
+    return (c1 * x - c2 * eps).clamp(-1, 1)
+
+
+def model_fn_xstart(sd, hp, x, noise_level, dt: DriverTables, dtab: DiffusionTables,
+                    noise_fn: Optional[Callable] = None, y_label=None):
+    """utils_model.py:207-258 with model_out_type='pred_xstart', ddim_sample=False.
+    noise_fn(x) mirrors the (dead but RNG-consuming) randn_like in p_sample (gaussian_diffusion.py:430)."""
+    t_step = find_nearest(dt.reduced, noise_level / 255.0)
+    vec_t = torch.tensor([t_step] * x.shape[0])
+    out = uo.unet_forward(sd, hp, x, vec_t, y_label)
+    eps = out[:, :3]
+    x0 = pred_xstart_from_eps(x, eps, t_step, dtab)
+    if noise_fn is not None:
+        noise_fn(x)
+    return x0
+
+
+# ------------------------------------------------------------------ FFT prox
+def splits(a, sf):
+    """utils_sisr.py:9-19: [N,C,H,W] -> [N,C,H/sf,W/sf,sf*sf] alias blocks."""
+    b = torch.stack(torch.chunk(a, sf, dim=2), dim=4)
+    return torch.cat(torch.chunk(b, sf, dim=3), dim=4)
+
+
+def p2o(psf, shape):
+    """utils_sisr.py:22-41: zero-pad PSF to `shape`, circularly centre it, fft2."""
+    otf = torch.zeros(psf.shape[:-2] + tuple(shape)).type_as(psf)
+    otf[..., :psf.shape[2], :psf.shape[3]].copy_(psf)
+    for axis, n in enumerate(psf.shape[2:]):
+        otf = torch.roll(otf, -int(n / 2), dims=axis + 2)
+    return torch.fft.fftn(otf, dim=(-2, -1))
+
+
+def pre_calculate(y, k, sf):
+    """utils_sisr.py:78-95."""
+    h, w = y.shape[-2:]
+    FB = p2o(k, (h * sf, w * sf))
+    FBC = torch.conj(FB)
+    F2B = torch.pow(torch.abs(FB), 2)
+    STy = torch.zeros((y.shape[0], y.shape[1], h * sf, w * sf)).type_as(y)
+    STy[..., 0::sf, 0::sf].copy_(y)
+    FBFy = FBC * torch.fft.fftn(STy, dim=(-2, -1))
+    return FB, FBC, F2B, FBFy
+
+
+def data_solution(x, FB, FBC, F2B, FBFy, alpha, sf):
+    """utils_sisr.py:65-75: closed-form argmin ||y - S(k*x)||^2 + alpha ||x - z||^2."""
+    FR = FBFy + torch.fft.fftn(alpha * x, dim=(-2, -1))
+    x1 = FB.mul(FR)
+    FBR = torch.mean(splits(x1, sf), dim=-1, keepdim=False)
+    invW = torch.mean(splits(F2B, sf), dim=-1, keepdim=False)
+    invWBR = FBR.div(invW + alpha)
+    FCBinvWBR = FBC * invWBR.repeat(1, 1, sf, sf)
+    FX = (FR - FCBinvWBR) / alpha
+    return torch.real(torch.fft.ifftn(FX, dim=(-2, -1)))
+
+
+def prox_fft(x0, pre, tau, sf, guidance=1.0):
+    """main_ddpir.py:395-400."""
+    FB, FBC, F2B, FBFy = pre
+    x0_p = x0 / 2 + 0.5
+    x0_p = data_solution(x0_p.float(), FB, FBC, F2B, FBFy, tau, sf)
+    x0_p = x0_p * 2 - 1
+    return x0 + guidance * (x0_p - x0)
+
+
+def prox_mask(x0, y, mask, tau, guidance=1.0):
+    """main_ddpir.py:392-394."""
+    x0_p = (mask * (2 * y - 1) + tau * x0).div(mask + tau)
+    return x0 + guidance * (x0_p - x0)
+
+
+# ------------------------------------------------------------------ Resizer (cubic, antialiased)
+def _cubic(x):
+    ax = np.abs(x)
+    ax2, ax3 = ax ** 2, ax ** 3
+    return ((1.5 * ax3 - 2.5 * ax2 + 1) * (ax <= 1) +
+            (-0.5 * ax3 + 2.5 * ax2 - 4 * ax + 2) * ((1 < ax) & (ax <= 2)))
+
+
+def resizer_contributions(in_len: int, out_len: int, scale: float):
+    """utils_resizer.py:104-167 for kernel='cubic', antialiasing when scale<1.
+    Returns (weights [out,taps] float64, indices [out,taps] int)."""
+    aa = scale < 1
+    kern = (lambda a: scale * _cubic(scale * a)) if aa else _cubic
+    kw = 4.0 / scale if aa else 4.0
+    outc = np.arange(1, out_len + 1)
+    shifted = outc - (out_len - in_len * scale) / 2
+    match = shifted / scale + 0.5 * (1 - 1 / scale)
+    left = np.floor(match - kw / 2)
+    ekw = np.ceil(kw) + 2
+    fov = np.squeeze(np.int16(np.expand_dims(left, 1) + np.arange(ekw) - 1))
+    w = kern(1.0 * np.expand_dims(match, 1) - fov - 1)
+    sw = np.sum(w, axis=1)
+    sw[sw == 0] = 1.0
+    w = 1.0 * w / np.expand_dims(sw, 1)
+    mirror = np.uint(np.concatenate((np.arange(in_len), np.arange(in_len - 1, -1, step=-1))))
+    fov = mirror[np.mod(fov, mirror.shape[0])]
+    nz = np.nonzero(np.any(w, axis=0))
+    w = np.squeeze(w[:, nz])
+    fov = np.squeeze(fov[:, nz])
+    return w, fov.astype(np.int64)
+
+
+def resizer_apply(x, sf_inv: float):
+    """utils_resizer.py:55-74 for a 4-D tensor and scalar scale: both spatial dims have equal
+    scale so the stable argsort processes dim 2 (H) first, then dim 3 (W)."""
+    out = x
+    for dim in (2, 3):
+        n = out.shape[dim]
+        m = int(np.ceil(n * sf_inv))
+        w, fov = resizer_contributions(n, m, sf_inv)
+        w_t = torch.tensor(w.T, dtype=torch.float32)                   # [taps,out]
+        fov_t = torch.tensor(fov.T.astype(np.int32), dtype=torch.long)   # [taps,out]
+        xt = torch.transpose(out, dim, 0)
+        wv = w_t.reshape(list(w_t.shape) + [1] * 3)
+        xt = torch.sum(xt[fov_t] * wv, dim=0)
+        out = torch.transpose(xt, dim, 0)
+    return out
+
+
+def prox_ibp(x0, y, rho, sf, gamma, in_iter):
+    """main_ddpir.py:401-406: iterative back-projection; up-sampler is F.interpolate default (nearest)."""
+    for _ in range(in_iter):
+        x0 = x0 / 2 + 0.5
+        x0 = x0 + gamma * F.interpolate(y - resizer_apply(x0, 1.0 / sf), scale_factor=sf) / (1 + rho)
+        x0 = x0 * 2 - 1
+    return x0
+
+
+# ------------------------------------------------------------------ loop
+def renoise(x, x0, dt: DriverTables, t_i, t_im1, eta, zeta, n1, n2):
+    """main_ddpir.py:451-456 verbatim arithmetic order (float32 tensors x numpy float64 sqrt)."""
+    eps = (x - dt.sqrt_ac[t_i] * x0) / dt.sqrt_1m_ac[t_i]
+    eta_sigma = eta * dt.sqrt_1m_ac[t_im1] / dt.sqrt_1m_ac[t_i] * torch.sqrt(dt.betas[t_i])
+    return dt.sqrt_ac[t_im1] * x0 + np.sqrt(1 - zeta) * (
+        torch.sqrt(dt.sqrt_1m_ac[t_im1] ** 2 - eta_sigma ** 2) * eps + eta_sigma * n1) \
+        + np.sqrt(zeta) * dt.sqrt_1m_ac[t_im1] * n2
+
+
+def init_x(cfg: LoopConfig, y, mask, dt: DriverTables, noise0, t_start=None):
+    """main_ddpir.py:293-315."""
+    if t_start is None:
+        t_start = cfg.T - 1
+    if cfg.task == "sr":
+        x = F.interpolate(y, size=(y.shape[2] * cfg.sf, y.shape[3] * cfg.sf), mode="bicubic", align_corners=False)
+    elif cfg.task == "deblur":
+        x = y
+    else:
+        x = y * mask
+    return dt.sqrt_ac[t_start] * (2 * x - 1) + dt.sqrt_1m_ac[t_start] * noise0
+
+
+def tensor2uint_batch(x01):
+    """utils_image.py:238-242: clamp, NCHW->NHWC, *255 round -> u8."""
+    img = x01.float().clamp(0, 1).cpu().numpy()
+    img = np.transpose(img, (0, 2, 3, 1))
+    return np.uint8((img * 255.0).round())
+
+
+def psnr_batch(a, b, max_pixel=2.0, eps=1e-10):
+    """utils_image.py:601-610."""
+    mse = torch.mean((a - b) ** 2, dim=(1, 2, 3))
+    v = torch.where(mse == 0, torch.full_like(mse, float("inf")), 20 * torch.log10(max_pixel / torch.sqrt(mse + eps)))
+    v = torch.where(torch.isnan(v), torch.zeros_like(v), v)
+    return float(torch.mean(v))
+
+
+def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = None, y_label=None,
+            trace: Optional[list] = None, denoiser: Optional[Callable] = None):
+    """One batch of main_ddpir.py:259-470 (generate_mode='DiffPIR', pred_xstart, iter_num_U=1).
+
+    y [B,3,h,w] in [0,1]; k [B,1,kh,kw] (deblur/sr-blur); mask [B,3,H,W] float {0,1} (inpaint).
+    noise_fn(like) -> N(0,1) tensor; called in the reference's draw order (SURVEY 8 a-R):
+    init, then per step: p_sample, n1 (eta term), n2 (zeta term).
+    `denoiser(x, t_i) -> x0` overrides the UNet (used to test the loop without a network).
+    Returns x_0 in [0,1] (un-clamped, main_ddpir.py:470)."""
+    dt, steps = step_tables(cfg)
+    dtab = DiffusionTables(cfg.T)
+    y = y.float()
+    if cfg.task == "inpaint":
+        mask = mask.float()
+    x = init_x(cfg, y, mask, dt, noise_fn(torch.empty(y.shape[0], 3, y.shape[2] * cfg.sf, y.shape[3] * cfg.sf)))
+    pre = None
+    if cfg.task in ("sr", "deblur"):
+        pre = pre_calculate(y, k.float(), cfg.sf)
+    for st in steps:
+        t_i = st["t_i"]
+        if denoiser is not None:
+            x0 = denoiser(x, t_i)
+            noise_fn(x)
+        else:
+            x0 = model_fn_xstart(sd, hp, x, st["curr_sigma"] * 255, dt, dtab, noise_fn, y_label)
+        if trace is not None:
+            trace.append(("x0", t_i, x0.clone()))
+        if not st["last"]:
+            tau = st["tau"].repeat(1, 1, 1, 1)
+            if cfg.task == "inpaint":
+                x0 = prox_mask(x0, y, mask, tau, cfg.guidance_scale)
+            elif cfg.task == "deblur" or cfg.sr_mode == "blur":
+                x0 = prox_fft(x0, pre, tau, cfg.sf, cfg.guidance_scale)
+            else:
+                x0 = prox_ibp(x0, y, st["tau"], cfg.sf, cfg.gamma, cfg.inIter)
+            n1 = noise_fn(x)
+            n2 = noise_fn(x)
+            x = renoise(x, x0, dt, t_i, st["t_im1"], cfg.eta, cfg.zeta, n1, n2)
+            if trace is not None:
+                trace.append(("x", st["t_im1"], x.clone()))
+    return x / 2 + 0.5

@@ -1,0 +1,142 @@
+"""The oracle restatement (oracle/*.py) against fixtures produced by the LIVE reference
+(tests/golden/*.npz, written by oracle/gen_golden.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import unet_oracle as uo
+from oracle import diffpir_oracle as do
+
+
+def seeded_noise_fn(seed):
+    g = torch.Generator().manual_seed(seed)
+    return lambda like: torch.randn(like.shape, generator=g, dtype=torch.float32)
+
+
+@pytest.mark.parametrize("tag,hp", [("tiny", uo.tiny_hp()), ("tinycc", uo.tiny_hp(class_cond=True)), ("ffhq", uo.ffhq_hp())])
+def test_unet_forward_matches_reference(golden, tag, hp):
+    g = golden("unet_" + tag)
+    sd = uo.synth_state_dict(hp, 0)
+    y = torch.from_numpy(g["y"]) if "y" in g else None
+    out = uo.unet_forward(sd, hp, torch.from_numpy(g["x"]), torch.from_numpy(g["t"]), y)
+    np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=1e-5)
+
+
+def test_ffhq_topology_counts():
+    hp = uo.ffhq_hp()
+    spec = uo.state_dict_spec(hp)
+    assert len(spec) == 362
+    assert sum(int(np.prod(s)) for _, s, _ in spec) == 93_563_910
+    assert abs(uo.unet_flops(hp, 256, 256) / 1e9 - 387.93) < 0.01
+    assert abs(uo.unet_flops(uo.imagenet256_hp(), 256, 256) / 1e9 - 2239.67) < 0.01
+
+
+def test_schedule_tables(golden):
+    g = golden("schedule")
+    for name, cfg in dict(deblur100=do.LoopConfig("deblur", 100, 12.75 / 255, 7.0, 0.3),
+                          inpaint20=do.LoopConfig("inpaint", 20, 0.0, 1.0, 1.0),
+                          sr100=do.LoopConfig("sr", 100, 12.75 / 255, 6.0, 0.25, sf=4)).items():
+        _, steps = do.step_tables(cfg)
+        assert [s["t_i"] for s in steps] == list(g[name + "_t"])
+        np.testing.assert_array_equal(np.array([float(s["tau"]) for s in steps], np.float32), g[name + "_tau"])
+        assert all(steps[i]["t_im1"] == steps[i + 1]["t_i"] for i in range(len(steps) - 1))
+    d = do.DiffusionTables()
+    np.testing.assert_array_equal(d.sqrt_recip_ac, g["sqrt_recip_ac"])
+    np.testing.assert_array_equal(d.sqrt_recipm1_ac, g["sqrt_recipm1_ac"])
+    dt = do.DriverTables()
+    np.testing.assert_array_equal(dt.sqrt_ac.numpy(), g["drv_sqrt_ac"])
+    np.testing.assert_array_equal(dt.sqrt_1m_ac.numpy(), g["drv_sqrt_1m_ac"])
+    # t_i = 999 - seq[i]
+    assert list(g["deblur100_t"][:3]) == [999, 899, 857] and g["deblur100_t"][-1] == 0
+
+
+def test_fft_prox_operators(golden):
+    g = golden("operators")
+    z = torch.from_numpy(g["deblur_z"])
+    pre = do.pre_calculate(torch.from_numpy(g["deblur_y"]), torch.from_numpy(g["deblur_k"]), 1)
+    np.testing.assert_allclose(pre[0].numpy(), g["deblur_FB"], atol=1e-6)
+    np.testing.assert_allclose(pre[3].numpy(), g["deblur_FBFy"], atol=1e-4)
+    for a in (1e-5, 0.02, 3.0):
+        out = do.data_solution(z, *pre, torch.tensor(a).float().repeat(1, 1, 1, 1), 1)
+        np.testing.assert_allclose(out.numpy(), g[f"deblur_out_{a}"], atol=1e-5)
+    k4 = torch.from_numpy(np.stack([g["k_bic4"], g["k_bic4"]]))[:, None]
+    pre = do.pre_calculate(torch.from_numpy(g["sr4_y"]), k4, 4)
+    for a in (1e-4, 0.05, 2.0):
+        out = do.data_solution(z, *pre, torch.tensor(a).float().repeat(1, 1, 1, 1), 4)
+        np.testing.assert_allclose(out.numpy(), g[f"sr4_out_{a}"], atol=1e-5)
+    pre = do.pre_calculate(torch.from_numpy(g["sf2_y"]), torch.from_numpy(g["sf2_k"]), 2)
+    out = do.data_solution(z, *pre, torch.tensor(0.1).float().repeat(1, 1, 1, 1), 2)
+    np.testing.assert_allclose(out.numpy(), g["sf2_out"], atol=1e-5)
+
+
+def test_wiener_identity_and_dense_solve():
+    """KATs from SURVEY section 4 (independent of the reference)."""
+    rng = np.random.default_rng(0)
+    k = rng.random((1, 1, 5, 5)); k /= k.sum()
+    y = rng.random((1, 1, 16, 16)); z = rng.random((1, 1, 16, 16))
+    a = 0.3
+    kt, yt, zt = (torch.from_numpy(v) for v in (k, y, z))          # float64 throughout
+    pre = do.pre_calculate(yt, kt, 1)
+    out = do.data_solution(zt, *pre, torch.tensor(a, dtype=torch.float64).repeat(1, 1, 1, 1), 1)
+    FB = pre[0]
+    wien = torch.real(torch.fft.ifft2((torch.conj(FB) * torch.fft.fft2(yt) + a * torch.fft.fft2(zt)) / (FB.abs() ** 2 + a)))
+    assert float((out - wien).abs().max()) < 1e-12
+    # sf=2: dense normal equations (H^T H + a I) x = H^T y + a z, H = downsample o circular conv
+    ys = rng.random((1, 1, 8, 8))
+    pre = do.pre_calculate(torch.from_numpy(ys), kt, 2)
+    out = do.data_solution(zt, *pre, torch.tensor(a, dtype=torch.float64).repeat(1, 1, 1, 1), 2)
+    n = 16
+    Hm = np.zeros((64, n * n))
+    otf = torch.real(torch.fft.ifft2(pre[0]))[0, 0].numpy()     # circularly centred PSF
+    for oy in range(8):
+        for ox in range(8):
+            for dy in range(n):
+                for dx in range(n):
+                    Hm[oy * 8 + ox, dy * n + dx] = otf[(2 * oy - dy) % n, (2 * ox - dx) % n]
+    sol = np.linalg.solve(Hm.T @ Hm + a * np.eye(n * n), Hm.T @ ys.reshape(-1) + a * z.reshape(-1))
+    assert np.abs(out.numpy().reshape(-1) - sol).max() < 1e-10
+
+
+def test_resizer_and_init_and_output(golden):
+    g = golden("operators")
+    out = do.resizer_apply(torch.from_numpy(g["resizer_in"]), 0.25)
+    np.testing.assert_allclose(out.numpy(), g["resizer_out"], atol=1e-6)
+    w, fov = do.resizer_contributions(256, 64, 0.25)
+    assert w.shape == (64, 16) and fov.shape == (64, 16)             # 16 taps for x1/4
+    np.testing.assert_array_equal(do.tensor2uint_batch(torch.from_numpy(g["u8_in"])), g["u8_out"])
+    gt = torch.from_numpy(g["resizer_in"][:, :, :16, :16])
+    assert abs(do.psnr_batch(torch.from_numpy(g["u8_in"]) * 2 - 1, gt * 2 - 1) - float(g["psnr"])) < 1e-9
+
+
+def test_box_mask_fixture_is_binary(golden):
+    g = golden("operators")
+    m = g["mask_box"]
+    assert m.dtype == np.uint8 and set(np.unique(m)) == {0, 1}
+    assert (m[0, 0] == m[0, 1]).all() and (m[0, 0] == m[0, 2]).all()
+    assert int((m[0, 0] == 0).sum()) == 128 * 128                    # mask_len_range [128,129)
+    r = g["mask_random"]
+    assert int((r[0, 0] == 0).sum()) == 256 * 256 // 2
+
+
+@pytest.mark.parametrize("name,cfg,seed", [
+    ("deblur", do.LoopConfig("deblur", 6, 12.75 / 255, 7.0, 0.3), 42),
+    ("deblur_eta", do.LoopConfig("deblur", 5, 12.75 / 255, 7.0, 0.3, eta=0.7), 43),
+    ("inpaint", do.LoopConfig("inpaint", 6, 0.0, 1.0, 1.0), 44),
+    ("sr_blur", do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4), 45),
+    ("sr_cubic", do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", inIter=2, gamma=0.5), 46),
+])
+def test_whole_loop_matches_reference(golden, name, cfg, seed):
+    g = golden("loops")
+    ops = golden("operators")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    k = mask = None
+    if cfg.task == "deblur":
+        y, k = torch.from_numpy(g["deblur_y"]), torch.from_numpy(g["deblur_k"])
+    elif cfg.task == "inpaint":
+        y, mask = torch.from_numpy(g["inpaint_y"]), torch.from_numpy(g["inpaint_mask"]).float()
+    else:
+        y = torch.from_numpy(g["sr_y"])
+        k = torch.from_numpy(np.stack([ops["k_bic4"], ops["k_bic4"]]))[:, None]
+    out = do.restore(sd, hp, cfg, y, k=k, mask=mask, noise_fn=seeded_noise_fn(seed))
+    np.testing.assert_allclose(out.numpy(), g[name + "_out"], atol=2e-5)
