@@ -1,0 +1,114 @@
+"""ctypes binding of libdiffpir_hip.so (include/diffpir_engine.h).
+
+The library is built in-tree (diffpir_amd/csrc/libdiffpir_hip.so) by `__graft_entry__.build()` /
+`make -C diffpir_amd/csrc`.  There is NO fallback: if the library is missing, cannot be loaded, or
+no gfx950 device is visible, the product path raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libdiffpir_hip.so")
+
+
+class UNetDesc(C.Structure):
+    _fields_ = [("image_size", C.c_int32), ("in_channels", C.c_int32), ("model_channels", C.c_int32),
+                ("out_channels", C.c_int32), ("num_res_blocks", C.c_int32), ("num_head_channels", C.c_int32),
+                ("n_channel_mult", C.c_int32), ("channel_mult", C.c_float * 8),
+                ("n_attention_ds", C.c_int32), ("attention_ds", C.c_int32 * 8), ("num_classes", C.c_int32)]
+
+
+class Tensor(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("data", C.c_void_p), ("ndim", C.c_int32), ("shape", C.c_int64 * 4)]
+
+
+class Step(C.Structure):
+    _fields_ = [("t", C.c_int32), ("last", C.c_int32), ("c1", C.c_float), ("c2", C.c_float), ("tau", C.c_float),
+                ("sa_t", C.c_float), ("s1m_t", C.c_float), ("sa_p", C.c_float),
+                ("k1", C.c_float), ("q", C.c_float), ("es", C.c_float), ("k2", C.c_float)]
+
+
+class LoopDesc(C.Structure):
+    _fields_ = [("task", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("sf", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("in_iter", C.c_int32), ("gamma", C.c_float),
+                ("guidance", C.c_float), ("sa_start", C.c_float), ("s1m_start", C.c_float),
+                ("y_dev", C.c_void_p), ("k_dev", C.c_void_p), ("mask_dev", C.c_void_p), ("labels_host", C.c_void_p),
+                ("noise_init_dev", C.c_void_p), ("noise_n1_dev", C.c_void_p), ("noise_n2_dev", C.c_void_p),
+                ("seed", C.c_uint64), ("image_offset", C.c_int64), ("use_graph", C.c_int32),
+                ("skip_dead_final_eval", C.c_int32)]
+
+
+PROF_CLASSES = 8
+PROF_NAMES = ["conv3x3", "conv1x1", "groupnorm_stats", "attention", "fft_prox", "elementwise", "unet_forward", "loop_graph"]
+
+# name -> (restype, argtypes); every symbol declared in include/diffpir_engine.h
+SIGNATURES = {
+    "dpir_version": (C.c_int, []),
+    "dpir_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "dpir_destroy": (None, [C.c_void_p]),
+    "dpir_last_error": (C.c_char_p, [C.c_void_p]),
+    "dpir_sync": (C.c_int, [C.c_void_p]),
+    "dpir_stream": (C.c_void_p, [C.c_void_p]),
+    "dpir_malloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "dpir_free": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "dpir_h2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dpir_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dpir_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dpir_load_unet": (C.c_int, [C.c_void_p, C.POINTER(UNetDesc), C.POINTER(Tensor), C.c_int]),
+    "dpir_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_model_fn_xstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                       C.c_int, C.c_int, C.c_int]),
+    "dpir_unet_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
+    "dpir_prox_fft_precalc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                        C.c_int, C.POINTER(C.c_void_p)]),
+    "dpir_prox_free": (None, [C.c_void_p, C.c_void_p]),
+    "dpir_prox_read": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]),
+    "dpir_data_solution": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]),
+    "dpir_prox_fft_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float]),
+    "dpir_prox_mask": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int]),
+    "dpir_resize_down": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_prox_ibp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_bicubic_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_renoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_run_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.c_int, C.c_void_p, C.c_void_p]),
+    "dpir_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpir_prof_reset": (C.c_int, [C.c_void_p]),
+    "dpir_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dpir_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
+}
+
+_lib = None
+
+
+class EngineLibraryError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library and bind every declared symbol.  Raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise EngineLibraryError(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"or `make -C diffpir_amd/csrc`.  There is no CPU fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as ex:  # pragma: no cover
+        raise EngineLibraryError(f"cannot load {LIB_PATH}: {ex}") from ex
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as ex:
+            raise EngineLibraryError(f"{LIB_PATH} does not export {name}") from ex
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dpir_version() != 1:
+        raise EngineLibraryError("ABI version mismatch")
+    _lib = lib
+    return lib

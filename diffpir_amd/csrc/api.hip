@@ -1,0 +1,572 @@
+// C ABI (include/diffpir_engine.h): lifecycle, memory plumbing, operator entry points and the
+// restoration loop with hipGraph capture.  Each entry cites the reference interface it replaces in
+// the header; this file only validates, dispatches to the launchers and keeps the error string.
+#include "engine.h"
+#include <math.h>
+#include <string.h>
+
+using namespace dpir;
+
+static int fail(dpir_engine* e, const Status& s) {
+    if (e) e->last_error = s.msg;
+    return s.code;
+}
+#define API_TRY(e, expr)                          \
+    do {                                          \
+        Status _s = (expr);                       \
+        if (!_s.ok()) return fail((e), _s);       \
+    } while (0)
+#define API_HIP(e, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t _h = (expr);                                                           \
+        if (_h != hipSuccess)                                                             \
+            return fail((e), Status{DPIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_h)}); \
+    } while (0)
+
+static void prox_release(dpir::ProxState* st);
+static int ilog2u(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+Status dpir_engine::fft_plan(int N, FftPlan* out) {
+    auto it = fft_plans.find(N);
+    if (it != fft_plans.end()) { *out = it->second; return Status{}; }
+    if (N < 2 || (N & (N - 1))) return Status{DPIR_ERR_UNSUPPORTED, "FFT size must be a power of two"};
+    std::vector<float2> tw(N / 2);
+    for (int k = 0; k < N / 2; ++k) {
+        double a = -2.0 * M_PI * (double)k / (double)N;
+        tw[k] = make_float2((float)cos(a), (float)sin(a));
+    }
+    FftPlan p; p.N = N; p.logN = ilog2u(N);
+    void* d = nullptr;
+    DPIR_HIP(hipMalloc(&d, tw.size() * sizeof(float2)));
+    DPIR_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    p.tw = reinterpret_cast<float2*>(d);
+    fft_plans[N] = p;
+    *out = p;
+    return Status{};
+}
+
+Status dpir_engine::resizer(int in_len, int sf, ResizerTab* out) {
+    auto key = std::make_pair(in_len, sf);
+    auto it = resizers.find(key);
+    if (it != resizers.end()) { *out = it->second; return Status{}; }
+    if (sf < 1 || in_len % sf) return invalid("Resizer: length not divisible by sf");
+    ResizerTab t; t.in_len = in_len; t.out_len = in_len / sf;
+    std::vector<float> w; std::vector<int> idx;
+    resizer_band(in_len, t.out_len, 1.0 / sf, w, idx, t.taps);
+    void *dw = nullptr, *di = nullptr;
+    DPIR_HIP(hipMalloc(&dw, w.size() * sizeof(float)));
+    DPIR_HIP(hipMalloc(&di, idx.size() * sizeof(int)));
+    DPIR_HIP(hipMemcpy(dw, w.data(), w.size() * sizeof(float), hipMemcpyHostToDevice));
+    DPIR_HIP(hipMemcpy(di, idx.data(), idx.size() * sizeof(int), hipMemcpyHostToDevice));
+    t.w = reinterpret_cast<float*>(dw); t.idx = reinterpret_cast<int*>(di);
+    resizers[key] = t;
+    *out = t;
+    return Status{};
+}
+
+__global__ void fill_int_kernel(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+extern "C" {
+
+int dpir_version(void) { return DPIR_ABI_VERSION; }
+
+int dpir_create(int device, dpir_engine** out) {
+    if (!out) return DPIR_ERR_INVALID;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return DPIR_ERR_HIP;
+    if (hipSetDevice(device) != hipSuccess) return DPIR_ERR_HIP;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return DPIR_ERR_HIP;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return DPIR_ERR_UNSUPPORTED;   // kernels are built for gfx950 only
+    dpir_engine* e = new (std::nothrow) dpir_engine();
+    if (!e) return DPIR_ERR_NOMEM;
+    e->device = device;
+    if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DPIR_ERR_HIP; }
+    e->prof.stream = e->stream;
+    *out = e;
+    return DPIR_OK;
+}
+
+void dpir_destroy(dpir_engine* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    (void)hipStreamSynchronize(e->stream);
+    unet_free(e);
+    e->ws.release();
+    for (auto& kv : e->fft_plans) (void)hipFree(kv.second.tw);
+    for (auto& kv : e->resizers) { (void)hipFree(kv.second.w); (void)hipFree(kv.second.idx); }
+    for (void* p : e->user_allocs) (void)hipFree(p);
+    e->invalidate_graphs();
+    prox_release(&e->loop_prox);
+    (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+const char* dpir_last_error(const dpir_engine* e) { return e ? e->last_error.c_str() : "null engine"; }
+
+int dpir_sync(dpir_engine* e) {
+    if (!e) return DPIR_ERR_INVALID;
+    API_HIP(e, hipStreamSynchronize(e->stream));
+    return DPIR_OK;
+}
+void* dpir_stream(dpir_engine* e) { return e ? (void*)e->stream : nullptr; }
+
+int dpir_malloc(dpir_engine* e, size_t bytes, void** dev_out) {
+    if (!e || !dev_out) return DPIR_ERR_INVALID;
+    (void)hipSetDevice(e->device);
+    void* p = nullptr;
+    if (hipMalloc(&p, bytes ? bytes : 1) != hipSuccess) return fail(e, Status{DPIR_ERR_NOMEM, "dpir_malloc: hipMalloc failed"});
+    e->user_allocs.push_back(p);
+    *dev_out = p;
+    return DPIR_OK;
+}
+int dpir_free(dpir_engine* e, void* dev) {
+    if (!e) return DPIR_ERR_INVALID;
+    for (size_t i = 0; i < e->user_allocs.size(); ++i)
+        if (e->user_allocs[i] == dev) {
+            (void)hipStreamSynchronize(e->stream);
+            (void)hipFree(dev);
+            e->user_allocs.erase(e->user_allocs.begin() + i);
+            return DPIR_OK;
+        }
+    return fail(e, invalid("dpir_free: pointer was not allocated by dpir_malloc"));
+}
+int dpir_h2d(dpir_engine* e, void* d, const void* h, size_t bytes) {
+    if (!e) return DPIR_ERR_INVALID;
+    API_HIP(e, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
+    API_HIP(e, hipStreamSynchronize(e->stream));   // the host buffer may be pageable / short-lived
+    return DPIR_OK;
+}
+int dpir_d2h(dpir_engine* e, void* h, const void* d, size_t bytes) {
+    if (!e) return DPIR_ERR_INVALID;
+    API_HIP(e, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
+    API_HIP(e, hipStreamSynchronize(e->stream));
+    return DPIR_OK;
+}
+int dpir_d2d(dpir_engine* e, void* dd, const void* ds, size_t bytes) {
+    if (!e) return DPIR_ERR_INVALID;
+    API_HIP(e, hipMemcpyAsync(dd, ds, bytes, hipMemcpyDeviceToDevice, e->stream));
+    return DPIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ UNet
+int dpir_load_unet(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* weights, int n_weights) {
+    if (!e || !desc || !weights || n_weights <= 0) return fail(e, invalid("dpir_load_unet: null argument"));
+    (void)hipSetDevice(e->device);
+    API_HIP(e, hipStreamSynchronize(e->stream));
+    e->invalidate_graphs();
+    Status s = unet_load(e, desc, weights, n_weights);
+    if (!s.ok()) { unet_free(e); return fail(e, s); }
+    return DPIR_OK;
+}
+
+static Status upload_ints(dpir_engine* e, const char* name, const int64_t* host, int B, int** dev) {
+    if (!host) { *dev = nullptr; return Status{}; }
+    DPIR_TRY(e->ws.getT(name, (size_t)B, dev));
+    std::vector<int> tmp(B);
+    for (int i = 0; i < B; ++i) tmp[i] = (int)host[i];
+    DPIR_HIP(hipMemcpyAsync(*dev, tmp.data(), B * sizeof(int), hipMemcpyHostToDevice, e->stream));
+    DPIR_HIP(hipStreamSynchronize(e->stream));
+    return Status{};
+}
+
+int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, const int64_t* y_host, float* out, int B, int H, int W) {
+    if (!e || !x || !t_host || !out) return fail(e, invalid("dpir_unet_forward: null argument"));
+    (void)hipSetDevice(e->device);
+    int *t_dev = nullptr, *y_dev = nullptr;
+    API_TRY(e, upload_ints(e, "api#t", t_host, B, &t_dev));
+    API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
+    if (y_host && e->net.loaded)
+        for (int i = 0; i < B; ++i)
+            if (y_host[i] < 0 || y_host[i] >= e->net.desc.num_classes) return fail(e, invalid("class label out of range"));
+    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out, B, H, W));
+    return DPIR_OK;
+}
+
+int dpir_model_fn_xstart(dpir_engine* e, const float* x, int t, float c1, float c2, const int64_t* y_host, float* x0, int B, int H, int W) {
+    if (!e || !x || !x0) return fail(e, invalid("dpir_model_fn_xstart: null argument"));
+    (void)hipSetDevice(e->device);
+    if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
+    std::vector<int64_t> tv(B, t);
+    int *t_dev = nullptr, *y_dev = nullptr;
+    API_TRY(e, upload_ints(e, "api#t", tv.data(), B, &t_dev));
+    API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
+    float* out6 = nullptr;
+    API_TRY(e, e->ws.getT("api#out6", (size_t)B * e->net.desc.out_channels * H * W, &out6));
+    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out6, B, H, W));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_xstart(e->stream, x, out6, e->net.desc.out_channels, c1, c2, x0, B, H * W));
+    return DPIR_OK;
+}
+
+int dpir_unet_read_tap(dpir_engine* e, const char* layer, float* host_dst, size_t cap, size_t* numel_out) {
+    if (!e || !layer) return fail(e, invalid("dpir_unet_read_tap: null argument"));
+    auto it = e->taps.find(layer);
+    if (it == e->taps.end()) return fail(e, invalid(std::string("no such tap: ") + layer));
+    if (numel_out) *numel_out = it->second.numel;
+    if (!host_dst) return DPIR_OK;
+    if (cap < it->second.numel) return fail(e, invalid("dpir_unet_read_tap: destination too small"));
+    return dpir_d2h(e, host_dst, it->second.p, it->second.numel * sizeof(float));
+}
+
+double dpir_unet_flops(dpir_engine* e, int H, int W) { return e ? unet_flops(e->net, H, W) : 0.0; }
+
+// ------------------------------------------------------------------------------------------ FFT prox
+static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, ProxState* st) {
+    if (sf < 1 || H % sf || W % sf) return invalid("pre_calculate: image size not divisible by sf");
+    FftPlan ph, pw;
+    DPIR_TRY(e->fft_plan(H, &ph));
+    DPIR_TRY(e->fft_plan(W, &pw));
+    hipStream_t s = e->stream;
+    ProfScope ps(&e->prof, PC_FFT);
+    DPIR_TRY(launch_psf_embed(s, k, kh, kw, st->FB, B, H, W));
+    DPIR_TRY(launch_fft_rows(s, pw, st->FB, nullptr, 1.f, 0.f, B, H, W, false));
+    DPIR_TRY(launch_fft_cols(s, ph, st->FB, B, H, W, false));
+    DPIR_TRY(launch_upsample_embed(s, y, sf, st->FBFy, B * 3, H / sf, W / sf));
+    DPIR_TRY(launch_fft_rows(s, pw, st->FBFy, nullptr, 1.f, 0.f, B * 3, H, W, false));
+    DPIR_TRY(launch_fft_cols(s, ph, st->FBFy, B * 3, H, W, false));
+    DPIR_TRY(launch_precalc_finish(s, st->FB, st->FBFy, st->F2B, B, H, W));
+    return Status{};
+}
+
+static Status prox_alloc(int sf, int B, int H, int W, ProxState* st) {
+    size_t hw = (size_t)H * W;
+    st->B = B; st->H = H; st->W = W; st->sf = sf;
+    if (hipMalloc((void**)&st->FB, B * hw * sizeof(float2)) != hipSuccess ||
+        hipMalloc((void**)&st->F2B, B * hw * sizeof(float)) != hipSuccess ||
+        hipMalloc((void**)&st->FBFy, 3 * B * hw * sizeof(float2)) != hipSuccess)
+        return Status{DPIR_ERR_NOMEM, "pre_calculate: hipMalloc failed"};
+    return Status{};
+}
+static void prox_release(ProxState* st) {
+    if (st->FB) (void)hipFree(st->FB);
+    if (st->F2B) (void)hipFree(st->F2B);
+    if (st->FBFy) (void)hipFree(st->FBFy);
+    st->FB = nullptr; st->F2B = nullptr; st->FBFy = nullptr;
+}
+
+int dpir_prox_fft_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, dpir_prox** out) {
+    if (!e || !y || !k || !out) return fail(e, invalid("dpir_prox_fft_precalc: null argument"));
+    (void)hipSetDevice(e->device);
+    *out = nullptr;
+    dpir_prox* p = new (std::nothrow) dpir_prox();
+    if (!p) return fail(e, Status{DPIR_ERR_NOMEM, "out of host memory"});
+    Status s = prox_alloc(sf, B, H, W, &p->st);
+    if (s.ok()) s = prox_precalc(e, y, k, kh, kw, sf, B, H, W, &p->st);
+    if (!s.ok()) { prox_release(&p->st); delete p; return fail(e, s); }
+    *out = p;
+    return DPIR_OK;
+}
+void dpir_prox_free(dpir_engine* e, dpir_prox* p) {
+    if (!p) return;
+    if (e) (void)hipStreamSynchronize(e->stream);
+    prox_release(&p->st);
+    delete p;
+}
+
+static unsigned brev(unsigned v, int bits) {
+    unsigned r = 0;
+    for (int i = 0; i < bits; ++i) r |= ((v >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst, size_t cap_bytes) {
+    if (!e || !p || !host_dst) return fail(e, invalid("dpir_prox_read: null argument"));
+    const ProxState& st = p->st;
+    size_t hw = (size_t)st.H * st.W;
+    size_t planes = which == 2 ? (size_t)3 * st.B : (size_t)st.B;
+    size_t esz = which == 1 ? sizeof(float) : sizeof(float2);
+    const void* src = which == 0 ? (const void*)st.FB : (which == 1 ? (const void*)st.F2B : (const void*)st.FBFy);
+    if (which < 0 || which > 2) return fail(e, invalid("dpir_prox_read: which must be 0, 1 or 2"));
+    if (cap_bytes < planes * hw * esz) return fail(e, invalid("dpir_prox_read: destination too small"));
+    std::vector<char> tmp(planes * hw * esz);
+    int rc = dpir_d2h(e, tmp.data(), src, tmp.size());
+    if (rc != DPIR_OK) return rc;
+    // stored layout is bit-reversed along both axes (fft.hip): natural[u][v] = stored[brev(u)][brev(v)]
+    int lh = ilog2u(st.H), lw = ilog2u(st.W);
+    char* dst = reinterpret_cast<char*>(host_dst);
+    for (size_t pl = 0; pl < planes; ++pl)
+        for (int u = 0; u < st.H; ++u)
+            for (int v = 0; v < st.W; ++v)
+                memcpy(dst + (pl * hw + (size_t)u * st.W + v) * esz,
+                       tmp.data() + (pl * hw + (size_t)brev(u, lh) * st.W + brev(v, lw)) * esz, esz);
+    return DPIR_OK;
+}
+
+// out = blend ? base + g*((ifft)*oa+ob - base) : (ifft)*oa+ob ; input pre-map v = (x*pa+pb)*alpha
+static Status data_solution_impl(dpir_engine* e, const ProxState& st, const float* x, float pa, float pb, float alpha, float* out,
+                                 float oa, float ob, const float* blend_base, float g) {
+    if (!(alpha > 0.f)) return invalid("data_solution: alpha must be > 0");
+    FftPlan ph, pw;
+    DPIR_TRY(e->fft_plan(st.H, &ph));
+    DPIR_TRY(e->fft_plan(st.W, &pw));
+    float2* buf = nullptr;
+    DPIR_TRY(e->ws.getT("prox#buf", (size_t)st.B * 3 * st.H * st.W, &buf));
+    hipStream_t s = e->stream;
+    ProfScope ps(&e->prof, PC_FFT);
+    DPIR_TRY(launch_fft_rows_real3(s, pw, buf, x, pa, pb, alpha, st.B * 3, st.H, st.W));
+    SolveArgs a{st.FB, st.F2B, st.FBFy, alpha, st.sf};
+    DPIR_TRY(launch_fft_cols_solve(s, ph, buf, a, st.B, st.H, st.W));
+    float scale = 1.0f / ((float)st.H * (float)st.W);
+    DPIR_TRY(launch_ifft_rows_real(s, pw, buf, out, scale, oa, ob, blend_base, g, st.B * 3, st.H, st.W));
+    return Status{};
+}
+
+int dpir_data_solution(dpir_engine* e, const dpir_prox* p, const float* x, float alpha, float* out) {
+    if (!e || !p || !x || !out) return fail(e, invalid("dpir_data_solution: null argument"));
+    (void)hipSetDevice(e->device);
+    API_TRY(e, data_solution_impl(e, p->st, x, 1.f, 0.f, alpha, out, 1.f, 0.f, nullptr, 0.f));
+    return DPIR_OK;
+}
+int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0, float tau, float guidance) {
+    if (!e || !p || !x0) return fail(e, invalid("dpir_prox_fft_apply: null argument"));
+    (void)hipSetDevice(e->device);
+    API_TRY(e, data_solution_impl(e, p->st, x0, 0.5f, 0.5f, tau, x0, 2.f, -1.f, x0, guidance));
+    return DPIR_OK;
+}
+
+int dpir_prox_mask(dpir_engine* e, float* x0, const float* y, const uint8_t* mask, float tau, float guidance, int B, int H, int W) {
+    if (!e || !x0 || !y || !mask) return fail(e, invalid("dpir_prox_mask: null argument"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_prox_mask(e->stream, x0, y, mask, tau, guidance, (size_t)B * 3 * H * W));
+    return DPIR_OK;
+}
+
+static Status resize_down_impl(dpir_engine* e, const float* x, float pa, float pb, float* out, int sf, int B, int H, int W) {
+    ResizerTab th, tw;
+    DPIR_TRY(e->resizer(H, sf, &th));
+    DPIR_TRY(e->resizer(W, sf, &tw));
+    float* mid = nullptr;
+    DPIR_TRY(e->ws.getT("resize#mid", (size_t)B * 3 * (H / sf) * W, &mid));
+    ProfScope ps(&e->prof, PC_ELEM);
+    // dim 2 (H) first, then dim 3 (W): utils_resizer.py:29-30 (stable argsort of equal scale factors)
+    DPIR_TRY(launch_band_resample(e->stream, x, th.w, th.idx, th.taps, B * 3, H, H / sf, W, pa, pb, mid));
+    DPIR_TRY(launch_band_resample(e->stream, mid, tw.w, tw.idx, tw.taps, B * 3 * (H / sf), W, W / sf, 1, 1.f, 0.f, out));
+    return Status{};
+}
+
+int dpir_resize_down(dpir_engine* e, const float* x, float* out, int sf, int B, int H, int W) {
+    if (!e || !x || !out) return fail(e, invalid("dpir_resize_down: null argument"));
+    (void)hipSetDevice(e->device);
+    API_TRY(e, resize_down_impl(e, x, 1.f, 0.f, out, sf, B, H, W));
+    return DPIR_OK;
+}
+
+static Status prox_ibp_impl(dpir_engine* e, float* x0, const float* y, float rho, float gamma, int in_iter, int sf, int B, int H, int W) {
+    float* d = nullptr;
+    DPIR_TRY(e->ws.getT("ibp#down", (size_t)B * 3 * (H / sf) * (W / sf), &d));
+    for (int it = 0; it < in_iter; ++it) {
+        DPIR_TRY(resize_down_impl(e, x0, 0.5f, 0.5f, d, sf, B, H, W));      // down(x0/2+.5)
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_ibp_update(e->stream, x0, y, d, gamma, rho, sf, B * 3, H, W));
+    }
+    return Status{};
+}
+int dpir_prox_ibp(dpir_engine* e, float* x0, const float* y, float rho, float gamma, int in_iter, int sf, int B, int H, int W) {
+    if (!e || !x0 || !y) return fail(e, invalid("dpir_prox_ibp: null argument"));
+    (void)hipSetDevice(e->device);
+    API_TRY(e, prox_ibp_impl(e, x0, y, rho, gamma, in_iter, sf, B, H, W));
+    return DPIR_OK;
+}
+
+int dpir_bicubic_up(dpir_engine* e, const float* y, float* out, int sf, int B, int h, int w) {
+    if (!e || !y || !out) return fail(e, invalid("dpir_bicubic_up: null argument"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_bicubic_up(e->stream, y, out, B * 3, h, w, sf));
+    return DPIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ loop arithmetic
+static RenoiseCoef coef_of(const dpir_step& s) { return RenoiseCoef{s.sa_t, s.s1m_t, s.sa_p, s.k1, s.q, s.es, s.k2}; }
+
+int dpir_renoise(dpir_engine* e, float* x, const float* x0, const dpir_step* s, const float* n1, const float* n2, int B, int H, int W) {
+    if (!e || !x || !x0 || !s || !n2) return fail(e, invalid("dpir_renoise: null argument"));
+    if (s->es != 0.f && !n1) return fail(e, invalid("dpir_renoise: eta_sigma != 0 needs n1"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_renoise(e->stream, x, x0, coef_of(*s), s->es != 0.f ? n1 : nullptr, n2, (size_t)B * 3 * H * W));
+    return DPIR_OK;
+}
+int dpir_finalize(dpir_engine* e, const float* x, float* of, uint8_t* ou, int B, int H, int W) {
+    if (!e || !x) return fail(e, invalid("dpir_finalize: null argument"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_finalize(e->stream, x, of, ou, B, H * W));
+    return DPIR_OK;
+}
+int dpir_randn(dpir_engine* e, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, int C, int H, int W) {
+    if (!e || !out) return fail(e, invalid("dpir_randn: null argument"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_randn(e->stream, out, seed, stream_id, image_offset, B, (size_t)C * H * W));
+    return DPIR_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------ whole loop
+namespace {
+struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; };
+
+Status loop_body(dpir_engine* e, const dpir_loop_desc& d, const dpir_step* steps, int n_steps, const LoopBufs& b,
+                 ProxState* prox, int first, int last_excl, bool do_init, bool do_finalize, float* out_f32, uint8_t* out_u8) {
+    hipStream_t s = e->stream;
+    const int B = d.B, H = d.H, W = d.W;
+    const size_t total = (size_t)B * 3 * H * W;
+    if (do_init) {
+        const float* src = d.y_dev;
+        if (d.task == DPIR_TASK_SR_BLUR || d.task == DPIR_TASK_SR_CUBIC) {
+            ProfScope ps(&e->prof, PC_ELEM);
+            DPIR_TRY(launch_bicubic_up(s, d.y_dev, b.init_src, B * 3, H / d.sf, W / d.sf, d.sf));   // main_ddpir.py:295
+            src = b.init_src;
+        }
+        const float* n0 = d.noise_init_dev;
+        if (!n0) { DPIR_TRY(launch_randn(s, b.n2, d.seed, 0, d.image_offset, B, (size_t)3 * H * W)); n0 = b.n2; }
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_init_x(s, src, d.task == DPIR_TASK_INPAINT ? d.mask_dev : nullptr, n0, d.sa_start, d.s1m_start, b.x, total));
+        if (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR)
+            DPIR_TRY(prox_precalc(e, d.y_dev, d.k_dev, d.kh, d.kw, d.sf, B, H, W, prox));
+    }
+    for (int i = first; i < last_excl; ++i) {
+        const dpir_step& st = steps[i];
+        if (st.last && d.skip_dead_final_eval) continue;
+        hipLaunchKernelGGL(fill_int_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, (int)st.t, B);
+        DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
+        {
+            ProfScope ps(&e->prof, PC_ELEM);
+            DPIR_TRY(launch_xstart(s, b.x, b.out6, e->net.desc.out_channels, st.c1, st.c2, b.x0, B, H * W));
+        }
+        if (st.last) continue;
+        if (d.task == DPIR_TASK_INPAINT) {
+            ProfScope ps(&e->prof, PC_ELEM);
+            DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, st.tau, d.guidance, total));
+        } else if (d.task == DPIR_TASK_SR_CUBIC) {
+            DPIR_TRY(prox_ibp_impl(e, b.x0, d.y_dev, st.tau, d.gamma, d.in_iter, d.sf, B, H, W));
+        } else {
+            DPIR_TRY(data_solution_impl(e, *prox, b.x0, 0.5f, 0.5f, st.tau, b.x0, 2.f, -1.f, b.x0, d.guidance));
+        }
+        const float *n1 = nullptr, *n2 = nullptr;
+        ProfScope ps(&e->prof, PC_ELEM);
+        if (st.es != 0.f) {
+            if (d.noise_n1_dev) n1 = d.noise_n1_dev + (size_t)i * total;
+            else { DPIR_TRY(launch_randn(s, b.n1, d.seed, 1 + 2 * (uint64_t)i, d.image_offset, B, (size_t)3 * H * W)); n1 = b.n1; }
+        }
+        if (d.noise_n2_dev) n2 = d.noise_n2_dev + (size_t)i * total;
+        else { DPIR_TRY(launch_randn(s, b.n2, d.seed, 2 + 2 * (uint64_t)i, d.image_offset, B, (size_t)3 * H * W)); n2 = b.n2; }
+        DPIR_TRY(launch_renoise(s, b.x, b.x0, coef_of(st), n1, n2, total));
+    }
+    if (do_finalize) {
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_finalize(s, b.x, out_f32, out_u8, B, H * W));
+    }
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+uint64_t fnv(uint64_t h, const void* p, size_t n) {
+    const unsigned char* c = reinterpret_cast<const unsigned char*>(p);
+    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
+    return h;
+}
+}  // namespace
+
+extern "C" {
+
+int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* steps, int n_steps, float* out_f32, uint8_t* out_u8) {
+    if (!e || !dd || !steps || n_steps <= 0) return fail(e, invalid("dpir_run_loop: null argument"));
+    (void)hipSetDevice(e->device);
+    const dpir_loop_desc& d = *dd;
+    if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
+    if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.sf < 1 || d.H % d.sf || d.W % d.sf) return fail(e, invalid("dpir_run_loop: bad shape"));
+    if (!d.y_dev) return fail(e, invalid("dpir_run_loop: y is required"));
+    if ((d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && !d.k_dev) return fail(e, invalid("dpir_run_loop: task needs a PSF"));
+    if (d.task == DPIR_TASK_INPAINT && !d.mask_dev) return fail(e, invalid("dpir_run_loop: inpainting needs a mask"));
+    if (d.task < 0 || d.task > 3) return fail(e, invalid("dpir_run_loop: unknown task"));
+    if ((e->net.desc.num_classes > 0) != (d.labels_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
+    const int B = d.B, H = d.H, W = d.W;
+    const size_t total = (size_t)B * 3 * H * W;
+    LoopBufs b{};
+    API_TRY(e, e->ws.getT("loop#x", total, &b.x));
+    API_TRY(e, e->ws.getT("loop#x0", total, &b.x0));
+    API_TRY(e, e->ws.getT("loop#out6", (size_t)B * e->net.desc.out_channels * H * W, &b.out6));
+    API_TRY(e, e->ws.getT("loop#n1", total, &b.n1));
+    API_TRY(e, e->ws.getT("loop#n2", total, &b.n2));
+    API_TRY(e, e->ws.getT("loop#init", total, &b.init_src));
+    API_TRY(e, e->ws.getT("loop#t", (size_t)B, &b.t_dev));
+    API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
+    bool need_prox = d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR;
+    ProxState& prox = e->loop_prox;
+    if (need_prox && (prox.B != B || prox.H != H || prox.W != W || !prox.FB)) {
+        API_HIP(e, hipStreamSynchronize(e->stream));
+        prox_release(&prox);
+        API_TRY(e, prox_alloc(d.sf, B, H, W, &prox));
+    }
+    prox.sf = d.sf;
+
+    if (!d.use_graph) {
+        API_TRY(e, loop_body(e, d, steps, n_steps, b, &prox, 0, n_steps, true, true, out_f32, out_u8));
+        return DPIR_OK;
+    }
+    // ---- hipGraph path: the whole batch (init -> n_steps -> finalize) is one graph, cached by content
+    uint64_t key = fnv(1469598103934665603ull, &d, sizeof(d));
+    key = fnv(key, steps, sizeof(dpir_step) * n_steps);
+    key = fnv(key, &out_f32, sizeof(out_f32));
+    key = fnv(key, &out_u8, sizeof(out_u8));
+    key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
+    auto it = e->graphs.find(key);
+    if (it == e->graphs.end()) {
+        // warm-up: run the first step eagerly so that every workspace buffer exists before capture
+        bool prof_on = e->prof.on;
+        e->prof.on = false;
+        bool taps_on = e->collect_taps;
+        e->collect_taps = false;
+        Status ws = loop_body(e, d, steps, n_steps, b, &prox, 0, 1, true, false, nullptr, nullptr);
+        if (ws.ok() && hipStreamSynchronize(e->stream) != hipSuccess) ws = Status{DPIR_ERR_HIP, "warm-up step failed"};
+        if (!ws.ok()) { e->prof.on = prof_on; e->collect_taps = taps_on; return fail(e, ws); }
+        e->ws.frozen = true;
+        hipGraph_t graph = nullptr;
+        hipError_t herr = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        Status cs;
+        if (herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(herr)};
+        else {
+            cs = loop_body(e, d, steps, n_steps, b, &prox, 0, n_steps, true, true, out_f32, out_u8);
+            herr = hipStreamEndCapture(e->stream, &graph);
+            if (cs.ok() && herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(herr)};
+        }
+        e->ws.frozen = false;
+        e->prof.on = prof_on;
+        e->collect_taps = taps_on;
+        if (!cs.ok()) { if (graph) (void)hipGraphDestroy(graph); return fail(e, cs); }
+        hipGraphExec_t exec = nullptr;
+        herr = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (herr != hipSuccess) return fail(e, Status{DPIR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(herr)});
+        dpir_engine::GraphEntry ge; ge.exec = exec;
+        it = e->graphs.insert({key, ge}).first;
+    }
+    ProfScope ps(&e->prof, PC_LOOP);
+    API_HIP(e, hipGraphLaunch(it->second.exec, e->stream));
+    return DPIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ profiling
+int dpir_prof_enable(dpir_engine* e, int on) {
+    if (!e) return DPIR_ERR_INVALID;
+    e->prof.collect();
+    e->prof.on = on != 0;
+    return DPIR_OK;
+}
+int dpir_prof_reset(dpir_engine* e) {
+    if (!e) return DPIR_ERR_INVALID;
+    e->prof.reset();
+    return DPIR_OK;
+}
+int dpir_prof_read(dpir_engine* e, double* ms_out, int64_t* count_out) {
+    if (!e || !ms_out || !count_out) return DPIR_ERR_INVALID;
+    e->prof.collect();
+    for (int i = 0; i < DPIR_PROF_CLASSES; ++i) { ms_out[i] = e->prof.ms[i]; count_out[i] = e->prof.cnt[i]; }
+    return DPIR_OK;
+}
+
+}  // extern "C"

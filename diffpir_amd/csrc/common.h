@@ -1,0 +1,128 @@
+// Shared declarations for the DiffPIR MI355X engine (gfx950 only; no compatibility layers).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+#include <vector>
+#include <map>
+#include <memory>
+
+#include "../../include/diffpir_engine.h"
+
+namespace dpir {
+
+// ---------------------------------------------------------------------------------------------
+// error plumbing: nothing throws across the C ABI
+struct Status {
+    int code = DPIR_OK;
+    std::string msg;
+    bool ok() const { return code == DPIR_OK; }
+};
+
+#define DPIR_HIP(expr)                                                                         \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            char _b[512];                                                                      \
+            snprintf(_b, sizeof(_b), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),    \
+                     __FILE__, __LINE__);                                                      \
+            return dpir::Status{DPIR_ERR_HIP, _b};                                             \
+        }                                                                                      \
+    } while (0)
+
+#define DPIR_TRY(expr)                           \
+    do {                                         \
+        dpir::Status _s = (expr);                \
+        if (!_s.ok()) return _s;                 \
+    } while (0)
+
+inline Status invalid(const std::string& m) { return Status{DPIR_ERR_INVALID, m}; }
+
+// ---------------------------------------------------------------------------------------------
+// profiling classes (include/diffpir_engine.h)
+enum ProfClass { PC_CONV3 = 0, PC_CONV1 = 1, PC_GN = 2, PC_ATTN = 3, PC_FFT = 4, PC_ELEM = 5, PC_UNET = 6, PC_LOOP = 7 };
+
+struct Profiler {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    struct Rec { hipEvent_t a, b; int cls; };
+    std::vector<Rec> recs;
+    std::vector<hipEvent_t> pool;
+    double ms[DPIR_PROF_CLASSES] = {0};
+    int64_t cnt[DPIR_PROF_CLASSES] = {0};
+
+    hipEvent_t get() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; (void)hipEventCreate(&e); return e;
+    }
+    int begin(int cls) {
+        if (!on) return -1;
+        Rec r; r.a = get(); r.b = get(); r.cls = cls;
+        (void)hipEventRecord(r.a, stream);
+        recs.push_back(r);
+        return (int)recs.size() - 1;
+    }
+    void end(int id) {
+        if (id < 0) return;
+        (void)hipEventRecord(recs[id].b, stream);
+    }
+    void collect() {
+        if (recs.empty()) return;
+        (void)hipStreamSynchronize(stream);
+        for (auto& r : recs) {
+            float t = 0; (void)hipEventElapsedTime(&t, r.a, r.b);
+            ms[r.cls] += t; cnt[r.cls] += 1;
+            pool.push_back(r.a); pool.push_back(r.b);
+        }
+        recs.clear();
+    }
+    void reset() { collect(); for (int i = 0; i < DPIR_PROF_CLASSES; ++i) { ms[i] = 0; cnt[i] = 0; } }
+};
+
+struct ProfScope {
+    Profiler* p; int id;
+    ProfScope(Profiler* p_, int cls) : p(p_), id(p_ ? p_->begin(cls) : -1) {}
+    ~ProfScope() { if (p) p->end(id); }
+};
+
+// ---------------------------------------------------------------------------------------------
+// conv launcher (conv.hip)
+struct ConvSrc {
+    const float* a = nullptr; int ca = 0;     // first tensor  [B, ca, Hs, Ws]
+    const float* b = nullptr; int cb = 0;     // second tensor [B, cb, Hs, Ws] (virtual concat) or null
+    int Hs = 0, Ws = 0;                       // source resolution
+    int mode = 0;                             // 0 plain, 1 nearest-up x2, 2 avg-pool 2x2
+    const float4* prm = nullptr;              // [B, ca+cb] {mean, a, b, act}: v = (v-mean)*a+b, then SiLU if act != 0; null = identity
+};
+struct ConvArgs {
+    ConvSrc src;
+    const float* w = nullptr;     // packed [Cin][taps][CoutP]
+    const float* bias = nullptr;  // [Cout]
+    float* out = nullptr;         // [B, Cout, H, W]
+    const float* res = nullptr;   // residual [B, Cout, Hr, Wr] or null
+    int res_mode = 0;             // 0 plain, 1 up, 2 down (same meaning as src.mode)
+    int B = 0, Cin = 0, Cout = 0, CoutP = 0, H = 0, W = 0;
+    int ks = 3;                   // 3 or 1
+};
+Status launch_conv(hipStream_t s, const ConvArgs& a);
+inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+// norm.hip
+struct CatSrc { const float* a; int ca; const float* b; int cb; };
+// stats[n*32+g] = {mean, rstd} over the (virtual-concat) group
+Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, float2* stats);
+// prm[n*C+c] = {mean, rstd*gamma*(1+scale), beta*(1+scale)+shift, silu?1:0}; film = [B, film_stride] rows with
+// scale at film[n*film_stride + film_off + c], shift at +C; film == null -> plain GroupNorm
+Status launch_gn_prm(hipStream_t s, const float2* stats, const float* gamma, const float* beta,
+                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm);
+// time embedding MLP: t_dev [B] int32 -> semb [B, ted] = silu(time_embed(timestep_embedding(t)) + label_emb[y])
+Status launch_time_embed(hipStream_t s, const int* t_dev, const int* y_dev, const float* freqs, const float* w0, const float* b0,
+                         const float* w2, const float* b2, const float* label_emb, int B, int mc, float* tmp, float* semb);
+// out[n, r] = dot(W[r,:], semb[n,:]) + bias[r], W [R, K]
+Status launch_rows_gemv(hipStream_t s, const float* W, const float* bias, const float* x, int B, int R, int K, float* out);
+
+// attn.hip: qkv [B, 3C, T] (legacy head-major order) -> out [B, C, T]
+Status launch_attention(hipStream_t s, const float* qkv, float* out, int B, int C, int T, int head_ch);
+
+}  // namespace dpir

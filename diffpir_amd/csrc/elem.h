@@ -1,0 +1,53 @@
+// Declarations for elem.hip / fft.hip launchers.
+#pragma once
+#include "common.h"
+
+namespace dpir {
+
+struct RenoiseCoef { float sa_t, s1m_t, sa_p, k1, q, es, k2; };
+
+Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW);
+Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total);
+Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total);
+Status launch_init_x(hipStream_t s, const float* src, const uint8_t* mask, const float* noise, float sa, float s1m, float* x, size_t total);
+Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW);
+Status launch_affine(hipStream_t s, const float* x, float a, float b, float* out, size_t total);
+Status launch_band_resample(hipStream_t s, const float* in, const float* w, const int* idx, int taps, int P, int L_in,
+                            int L_out, int inner, float pa, float pb, float* out);
+Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W);
+Status launch_bicubic_up(hipStream_t s, const float* in, float* out, int P, int h, int w, int sf);
+Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image);
+void resizer_band(int in_len, int out_len, double scale, std::vector<float>& w_out, std::vector<int>& idx_out, int& taps_out);
+
+// fft.hip ------------------------------------------------------------------------------------
+// Twiddle table for size N: tw[k] = exp(-2 pi i k / N), k < N/2 (device pointer, float2)
+struct FftPlan {
+    int N = 0, logN = 0;
+    float2* tw = nullptr;
+};
+// 2-D complex FFT building blocks operate on [P, H, W] complex64 planes (full c2c)
+// rows: in-place FFT along W of every row; `real_in` (optional) supplies real input x*pa+pb instead of `buf`
+Status launch_fft_rows(hipStream_t s, const FftPlan& pw, float2* buf, const float* real_in, float pa, float pb,
+                       int P, int H, int W, bool inverse);
+Status launch_fft_rows_real3(hipStream_t s, const FftPlan& pw, float2* buf, const float* real_in, float pa, float pb, float pm,
+                             int P, int H, int W);
+// columns forward only (used by pre_calculate)
+Status launch_fft_cols(hipStream_t s, const FftPlan& ph, float2* buf, int P, int H, int W, bool inverse);
+// fused column pass of data_solution: col-FFT -> closed-form spectral solve -> inverse col-FFT
+//   FR = FBFy + F(alpha*x);  FX = (FR - conj(FB) * tile(mean_alias(FB*FR)/(mean_alias(F2B)+alpha))) / alpha
+struct SolveArgs {
+    const float2* FB;    // [B,1,H,W]
+    const float* F2B;    // [B,1,H,W]
+    const float2* FBFy;  // [B,3,H,W]
+    float alpha; int sf;
+};
+Status launch_fft_cols_solve(hipStream_t s, const FftPlan& ph, float2* buf, const SolveArgs& a, int B, int H, int W);
+// inverse rows with real output: out = Re(ifft_row)*oa + ob, optionally blended: out = base + g*(val - base)
+Status launch_ifft_rows_real(hipStream_t s, const FftPlan& pw, const float2* buf, float* out, float scale, float oa, float ob,
+                             const float* blend_base, float g, int P, int H, int W);
+// pointwise spectrum helpers for pre_calculate
+Status launch_psf_embed(hipStream_t s, const float* k, int kh, int kw, float2* otf, int B, int H, int W);
+Status launch_upsample_embed(hipStream_t s, const float* y, int sf, float2* out, int P, int h, int w);
+Status launch_precalc_finish(hipStream_t s, const float2* FB, float2* FBFy_inout, float* F2B, int B, int H, int W);
+
+}  // namespace dpir

@@ -1,0 +1,101 @@
+// Engine state: device arena, UNet plan + weights, workspaces.
+#pragma once
+#include "common.h"
+#include "elem.h"
+
+namespace dpir {
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+
+// name -> device buffer, grown on demand (never during graph capture: a warm-up pass allocates)
+struct Workspace {
+    std::map<std::string, DevBuf> bufs;
+    size_t total = 0;
+    bool frozen = false;   // true while a graph is being captured: allocation is an error
+    uint64_t generation = 0;   // bumped whenever a buffer is (re)allocated: captured graphs become stale
+    Status get(const std::string& name, size_t bytes, void** out);
+    template <class T> Status getT(const std::string& name, size_t count, T** out) {
+        void* p = nullptr;
+        DPIR_TRY(get(name, count * sizeof(T), &p));
+        *out = reinterpret_cast<T*>(p);
+        return Status{};
+    }
+    void release();
+};
+
+struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3; };
+struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
+struct ResW {
+    std::string name;
+    int cin = 0, cout = 0, mode = 0;   // mode: 0 plain, 1 up, 2 down
+    GnW gn1; ConvW conv1; GnW gn2; ConvW conv2;
+    bool has_skip = false; ConvW skip;
+    int film_off = 0;
+};
+struct AttnW { std::string name; int c = 0; GnW norm; ConvW qkv; ConvW proj; };
+struct Layer { int kind; int idx; std::string name; };   // kind 0 conv_in, 1 res, 2 attn
+typedef std::vector<Layer> Block;
+
+struct UNet {
+    bool loaded = false;
+    dpir_unet_desc desc{};
+    std::vector<float> cm;       // resolved channel_mult
+    std::vector<Block> in_blocks, out_blocks;
+    Block mid;
+    ConvW conv_in;
+    std::vector<ResW> res;
+    std::vector<AttnW> attn;
+    GnW out_gn; ConvW out_conv;
+    float *te_w0 = nullptr, *te_b0 = nullptr, *te_w2 = nullptr, *te_b2 = nullptr, *label_emb = nullptr, *freqs = nullptr;
+    float *film_w = nullptr, *film_b = nullptr;
+    int film_rows = 0;
+    std::vector<void*> allocs;   // every weight allocation (freed on reload / destroy)
+};
+
+struct TapInfo { const float* p; size_t numel; };
+
+struct ProxState {   // dpir_prox
+    int B = 0, H = 0, W = 0, sf = 1;
+    float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
+};
+
+struct ResizerTab { int in_len = 0, out_len = 0, taps = 0; float* w = nullptr; int* idx = nullptr; };
+
+}  // namespace dpir
+
+struct dpir_prox { dpir::ProxState st; };
+
+struct dpir_engine {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string last_error;
+    dpir::Profiler prof;
+    dpir::UNet net;
+    dpir::Workspace ws;          // UNet activations + loop state
+    std::map<std::string, dpir::TapInfo> taps;
+    std::map<int, dpir::FftPlan> fft_plans;
+    std::map<std::pair<int, int>, dpir::ResizerTab> resizers;   // (in_len, sf)
+    std::vector<void*> user_allocs;
+    bool collect_taps = true;
+    struct GraphEntry { hipGraphExec_t exec = nullptr; };
+    std::map<uint64_t, GraphEntry> graphs;       // captured restoration loops, keyed by descriptor content
+    dpir::ProxState loop_prox;                   // spectra owned by dpir_run_loop
+    void invalidate_graphs() {
+        for (auto& g : graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        graphs.clear();
+    }
+
+    dpir::Status fft_plan(int N, dpir::FftPlan* out);
+    dpir::Status resizer(int in_len, int sf, dpir::ResizerTab* out);
+};
+
+namespace dpir {
+Status unet_load(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* weights, int n);
+void unet_free(dpir_engine* e);
+// t_dev/y_dev: device int32 [B]
+Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W);
+double unet_flops(const UNet& net, int H, int W);
+}  // namespace dpir

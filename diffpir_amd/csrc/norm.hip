@@ -1,0 +1,153 @@
+// GroupNorm statistics, GroupNorm/FiLM parameter folding, timestep-embedding MLP and the per-ResBlock
+// FiLM projections.
+//
+// Replaces: GroupNorm32 (guided_diffusion/nn.py:17-19,93-100: 32 groups, eps 1e-5, fp32),
+// timestep_embedding (nn.py:103-121), time_embed (unet.py:471-475, 648), emb_layers
+// (unet.py:199-205, 245).  The normalisation itself is NOT a pass over the tensor: only the statistics
+// are computed here (one read of the tensor, fp64 accumulation), and the affine + FiLM + SiLU are
+// folded into the consumer convolution's prologue (conv.hip) through the per-(image,channel)
+// parameter table written by gn_prm_kernel.
+#include "common.h"
+
+namespace dpir {
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// one block per (image, group); the group may straddle the two tensors of a virtual concat
+__global__ __launch_bounds__(256) void gn_stats_kernel(CatSrc src, int HW, float2* stats) {
+    const int C = src.ca + src.cb;
+    const int cg = C / 32;
+    const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
+    double s = 0.0, ss = 0.0;
+    for (int cc = 0; cc < cg; ++cc) {
+        int c = g * cg + cc;
+        const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HW
+                                        : src.b + ((size_t)n * src.cb + (c - src.ca)) * HW;
+        if ((HW & 3) == 0) {
+            const float4* p4 = reinterpret_cast<const float4*>(plane);
+            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
+                float4 v = p4[i];
+                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
+                ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+            }
+        } else {
+            for (int i = threadIdx.x; i < HW; i += 256) {
+                float v = plane[i];
+                s += v; ss += (double)v * v;
+            }
+        }
+    }
+    __shared__ double red[2][4];
+    s = wave_sum(s); ss = wave_sum(ss);
+    int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = s; red[1][w] = ss; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+        double SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+        double cnt = (double)cg * HW;
+        double mean = S / cnt;
+        double var = SS / cnt - mean * mean;
+        if (var < 0) var = 0;
+        stats[blockIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+    }
+}
+
+Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, float2* stats) {
+    int C = src.ca + src.cb;
+    if (C % 32) return invalid("GroupNorm32 needs channels % 32 == 0");
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * 32), dim3(256), 0, s, src, HW, stats);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+__global__ void gn_prm_kernel(const float2* stats, const float* gamma, const float* beta, const float* film,
+                              int film_stride, int film_off, int B, int C, float act, float4* prm) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    int n = i / C, c = i - n * C;
+    float2 st = stats[n * 32 + c / (C / 32)];
+    float a = st.y * gamma[c];
+    float b = beta[c];
+    if (film) {   // h = GN(h) * (1 + scale) + shift   (unet.py:250-251)
+        float sc = 1.0f + film[(size_t)n * film_stride + film_off + c];
+        float sh = film[(size_t)n * film_stride + film_off + C + c];
+        a = a * sc;
+        b = b * sc + sh;
+    }
+    prm[i] = make_float4(st.x, a, b, act);
+}
+
+Status launch_gn_prm(hipStream_t s, const float2* stats, const float* gamma, const float* beta,
+                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm) {
+    int n = B * C;
+    hipLaunchKernelGGL(gn_prm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, gamma, beta, film, film_stride,
+                       film_off, B, C, silu ? 1.0f : 0.0f, prm);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+// out[n, r] = act_out( dot(W[r,:], in[n,:]) + bias[r] (+ extra[idx[n], r]) ); one wave per (r, n)
+template <int ACT_OUT>
+__global__ __launch_bounds__(256) void rows_gemv_kernel(const float* W, const float* bias, const float* x, int R, int K,
+                                                         float* out, const float* extra, const int* extra_idx) {
+    int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    int n = blockIdx.y;
+    int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* wr = W + (size_t)r * K;
+    const float* xn = x + (size_t)n * K;
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) acc = fmaf(wr[k], xn[k], acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) {
+        float v = acc + bias[r];
+        if (extra) v += extra[(size_t)extra_idx[n] * R + r];
+        if (ACT_OUT) v = v / (1.0f + expf(-v));
+        out[(size_t)n * R + r] = v;
+    }
+}
+
+Status launch_rows_gemv(hipStream_t s, const float* W, const float* bias, const float* x, int B, int R, int K, float* out) {
+    hipLaunchKernelGGL(rows_gemv_kernel<0>, dim3((R + 3) / 4, B), dim3(256), 0, s, W, bias, x, R, K, out,
+                       (const float*)nullptr, (const int*)nullptr);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+// e[n, :] = [cos(t f) | sin(t f)], f_i = exp(-ln(10000) i / half)      (nn.py:103-121)
+// (freqs are tabulated on the host, correctly rounded, at load time)
+__global__ void timestep_embedding_kernel(const int* t, const float* freqs, int mc, float* e) {
+    int n = blockIdx.x;
+    int half = mc / 2;
+    float tv = (float)t[n];
+    for (int i = threadIdx.x; i < half; i += blockDim.x) {
+        float a = tv * freqs[i];
+        e[(size_t)n * mc + i] = cosf(a);
+        e[(size_t)n * mc + half + i] = sinf(a);
+    }
+    if ((mc & 1) && threadIdx.x == 0) e[(size_t)n * mc + mc - 1] = 0.f;
+}
+
+Status launch_time_embed(hipStream_t s, const int* t_dev, const int* y_dev, const float* freqs, const float* w0, const float* b0,
+                         const float* w2, const float* b2, const float* label_emb, int B, int mc, float* tmp, float* semb) {
+    int ted = 4 * mc;
+    float* e = tmp;                 // [B, mc]
+    float* h = tmp + (size_t)B * mc;  // [B, ted]
+    hipLaunchKernelGGL(timestep_embedding_kernel, dim3(B), dim3(64), 0, s, t_dev, freqs, mc, e);
+    // h = silu(W0 e + b0)
+    hipLaunchKernelGGL(rows_gemv_kernel<1>, dim3((ted + 3) / 4, B), dim3(256), 0, s, w0, b0, e, ted, mc, h,
+                       (const float*)nullptr, (const int*)nullptr);
+    // semb = silu(W2 h + b2 (+ label_emb[y]))  -- every consumer of emb applies SiLU first (unet.py:200)
+    hipLaunchKernelGGL(rows_gemv_kernel<1>, dim3((ted + 3) / 4, B), dim3(256), 0, s, w2, b2, h, ted, ted, semb,
+                       label_emb, y_dev);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+}  // namespace dpir

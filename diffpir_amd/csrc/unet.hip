@@ -1,0 +1,446 @@
+// UNet plan builder, weight repacker and forward executor.
+//
+// Replaces script_util.create_model (guided_diffusion/script_util.py:130-184), UNetModel.__init__'s
+// topology walk (unet.py:480-616), load_state_dict (main_ddpir.py:231-240) and UNetModel.forward
+// (unet.py:634-663) with ResBlock._forward (unet.py:236-256) and AttentionBlock._forward
+// (unet.py:299-305).  Every layer is a handful of launches of the kernels in conv.hip / norm.hip /
+// attn.hip; concat, pooling, upsampling, GroupNorm-apply, SiLU, FiLM, bias and residual adds never
+// exist as separate passes (see conv.hip).
+#include "engine.h"
+#include <math.h>
+#include <string.h>
+
+namespace dpir {
+
+// ------------------------------------------------------------------------------------------ workspace
+Status Workspace::get(const std::string& name, size_t bytes, void** out) {
+    auto it = bufs.find(name);
+    if (it != bufs.end() && it->second.bytes >= bytes) { *out = it->second.p; return Status{}; }
+    if (frozen) return Status{DPIR_ERR_STATE, "workspace allocation of '" + name + "' during graph capture"};
+    if (it != bufs.end()) { (void)hipFree(it->second.p); total -= it->second.bytes; bufs.erase(it); }
+    void* p = nullptr;
+    size_t rb = (bytes + 255) & ~(size_t)255;
+    hipError_t err = hipMalloc(&p, rb);
+    if (err != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc(" + std::to_string(rb) + ") for '" + name + "' failed"};
+    bufs[name] = DevBuf{p, rb};
+    total += rb;
+    ++generation;
+    *out = p;
+    return Status{};
+}
+void Workspace::release() {
+    for (auto& kv : bufs) (void)hipFree(kv.second.p);
+    bufs.clear();
+    total = 0;
+}
+
+// ------------------------------------------------------------------------------------------ load
+namespace {
+struct WeightMap {
+    std::map<std::string, const dpir_tensor*> m;
+    Status find(const std::string& key, std::vector<int64_t> shape, const float** out) const {
+        auto it = m.find(key);
+        if (it == m.end()) return invalid("state-dict key missing: " + key);
+        const dpir_tensor* t = it->second;
+        if (t->ndim != (int)shape.size()) return invalid("state-dict key " + key + ": wrong rank");
+        for (size_t i = 0; i < shape.size(); ++i)
+            if (t->shape[i] != shape[i]) return invalid("state-dict key " + key + ": wrong shape");
+        if (!t->data) return invalid("state-dict key " + key + ": null data");
+        *out = t->data;
+        return Status{};
+    }
+};
+
+Status upload(dpir_engine* e, const float* host, size_t n, float** dev) {
+    void* p = nullptr;
+    if (hipMalloc(&p, n * sizeof(float)) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for weights failed"};
+    e->net.allocs.push_back(p);
+    DPIR_HIP(hipMemcpy(p, host, n * sizeof(float), hipMemcpyHostToDevice));
+    *dev = reinterpret_cast<float*>(p);
+    return Status{};
+}
+
+// OIHW (or OI1 for conv1d) -> [Cin][taps][CoutP]
+Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int cin, int cout, int ks, bool one_d, ConvW* out) {
+    const float *w = nullptr, *b = nullptr;
+    std::vector<int64_t> shape = one_d ? std::vector<int64_t>{cout, cin, 1} : std::vector<int64_t>{cout, cin, ks, ks};
+    DPIR_TRY(wm.find(p + ".weight", shape, &w));
+    DPIR_TRY(wm.find(p + ".bias", {cout}, &b));
+    int taps = ks * ks;
+    int coutp = round_up(cout, 32);
+    std::vector<float> packed((size_t)cin * taps * coutp, 0.f);
+    for (int co = 0; co < cout; ++co)
+        for (int ci = 0; ci < cin; ++ci)
+            for (int t = 0; t < taps; ++t)
+                packed[((size_t)ci * taps + t) * coutp + co] = w[((size_t)co * cin + ci) * taps + t];
+    out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
+    DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
+    DPIR_TRY(upload(e, b, cout, &out->bias));
+    return Status{};
+}
+Status load_gn(dpir_engine* e, const WeightMap& wm, const std::string& p, int c, GnW* out) {
+    const float *g = nullptr, *b = nullptr;
+    if (c % 32) return invalid("GroupNorm32 channels not divisible by 32 at " + p);
+    DPIR_TRY(wm.find(p + ".weight", {c}, &g));
+    DPIR_TRY(wm.find(p + ".bias", {c}, &b));
+    out->c = c;
+    DPIR_TRY(upload(e, g, c, &out->gamma));
+    DPIR_TRY(upload(e, b, c, &out->beta));
+    return Status{};
+}
+}  // namespace
+
+void unet_free(dpir_engine* e) {
+    for (void* p : e->net.allocs) (void)hipFree(p);
+    e->net = UNet{};
+}
+
+Status unet_load(dpir_engine* e, const dpir_unet_desc* d, const dpir_tensor* weights, int n) {
+    unet_free(e);
+    UNet& net = e->net;
+    net.desc = *d;
+    if (d->in_channels != 3) return invalid("in_channels must be 3");
+    if (d->model_channels <= 0 || d->model_channels % 32) return invalid("model_channels must be a positive multiple of 32");
+    if (d->num_head_channels != 64) return Status{DPIR_ERR_UNSUPPORTED, "only num_head_channels=64 is supported"};
+    if (d->n_channel_mult > 8 || d->n_attention_ds > 8) return invalid("too many channel_mult / attention_ds entries");
+    if (d->n_channel_mult > 0) net.cm.assign(d->channel_mult, d->channel_mult + d->n_channel_mult);
+    else if (d->image_size == 512) net.cm = {0.5f, 1, 1, 2, 2, 4, 4};
+    else if (d->image_size == 256) net.cm = {1, 1, 2, 2, 4, 4};
+    else if (d->image_size == 128) net.cm = {1, 1, 2, 3, 4};
+    else if (d->image_size == 64) net.cm = {1, 2, 3, 4};
+    else return invalid("unsupported image_size for default channel_mult");
+    WeightMap wm;
+    for (int i = 0; i < n; ++i) wm.m[weights[i].name] = &weights[i];
+
+    const int mc = d->model_channels, ted = 4 * mc;
+    auto has_attn = [&](int ds) { for (int i = 0; i < d->n_attention_ds; ++i) if (d->attention_ds[i] == ds) return true; return false; };
+    int film_rows = 0;
+    std::vector<std::pair<std::string, int>> film_parts;   // (key prefix, cout)
+
+    auto add_res = [&](const std::string& p, int cin, int cout, int mode, Block& blk) -> Status {
+        ResW r; r.name = p; r.cin = cin; r.cout = cout; r.mode = mode;
+        DPIR_TRY(load_gn(e, wm, p + ".in_layers.0", cin, &r.gn1));
+        DPIR_TRY(load_conv(e, wm, p + ".in_layers.2", cin, cout, 3, false, &r.conv1));
+        DPIR_TRY(load_gn(e, wm, p + ".out_layers.0", cout, &r.gn2));
+        DPIR_TRY(load_conv(e, wm, p + ".out_layers.3", cout, cout, 3, false, &r.conv2));
+        r.has_skip = cin != cout;
+        if (r.has_skip) {
+            if (mode != 0) return invalid("resampling ResBlock with channel change is not part of this architecture");
+            DPIR_TRY(load_conv(e, wm, p + ".skip_connection", cin, cout, 1, false, &r.skip));
+        }
+        r.film_off = film_rows;
+        film_rows += 2 * cout;
+        film_parts.push_back({p + ".emb_layers.1", cout});
+        blk.push_back(Layer{1, (int)net.res.size(), p});
+        net.res.push_back(r);
+        return Status{};
+    };
+    auto add_attn = [&](const std::string& p, int c, Block& blk) -> Status {
+        AttnW a; a.name = p; a.c = c;
+        if (c % 64) return invalid("attention channels not divisible by 64");
+        DPIR_TRY(load_gn(e, wm, p + ".norm", c, &a.norm));
+        DPIR_TRY(load_conv(e, wm, p + ".qkv", c, 3 * c, 1, true, &a.qkv));
+        DPIR_TRY(load_conv(e, wm, p + ".proj_out", c, c, 1, true, &a.proj));
+        blk.push_back(Layer{2, (int)net.attn.size(), p});
+        net.attn.push_back(a);
+        return Status{};
+    };
+
+    // unet.py:480-536
+    int ch = (int)(net.cm[0] * mc);
+    const int input_ch = ch;
+    {
+        Block b0;
+        DPIR_TRY(load_conv(e, wm, "input_blocks.0.0", 3, ch, 3, false, &net.conv_in));
+        b0.push_back(Layer{0, 0, "input_blocks.0.0"});
+        net.in_blocks.push_back(b0);
+    }
+    std::vector<int> chans{ch};
+    int ds = 1;
+    const int nlev = (int)net.cm.size();
+    for (int level = 0; level < nlev; ++level) {
+        for (int k = 0; k < d->num_res_blocks; ++k) {
+            Block blk;
+            std::string p = "input_blocks." + std::to_string(net.in_blocks.size());
+            int cout = (int)(net.cm[level] * mc);
+            DPIR_TRY(add_res(p + ".0", ch, cout, 0, blk));
+            ch = cout;
+            if (has_attn(ds)) DPIR_TRY(add_attn(p + ".1", ch, blk));
+            net.in_blocks.push_back(blk);
+            chans.push_back(ch);
+        }
+        if (level != nlev - 1) {
+            Block blk;
+            std::string p = "input_blocks." + std::to_string(net.in_blocks.size());
+            DPIR_TRY(add_res(p + ".0", ch, ch, 2, blk));
+            net.in_blocks.push_back(blk);
+            chans.push_back(ch);
+            ds *= 2;
+        }
+    }
+    // unet.py:539-563
+    DPIR_TRY(add_res("middle_block.0", ch, ch, 0, net.mid));
+    DPIR_TRY(add_attn("middle_block.1", ch, net.mid));
+    DPIR_TRY(add_res("middle_block.2", ch, ch, 0, net.mid));
+    // unet.py:566-610
+    for (int level = nlev - 1; level >= 0; --level) {
+        for (int i = 0; i <= d->num_res_blocks; ++i) {
+            Block blk;
+            std::string p = "output_blocks." + std::to_string(net.out_blocks.size());
+            int ich = chans.back(); chans.pop_back();
+            int cout = (int)(mc * net.cm[level]);
+            int j = 0;
+            DPIR_TRY(add_res(p + "." + std::to_string(j++), ch + ich, cout, 0, blk));
+            ch = cout;
+            if (has_attn(ds)) DPIR_TRY(add_attn(p + "." + std::to_string(j++), ch, blk));
+            if (level && i == d->num_res_blocks) {
+                DPIR_TRY(add_res(p + "." + std::to_string(j++), ch, ch, 1, blk));
+                ds /= 2;
+            }
+            net.out_blocks.push_back(blk);
+        }
+    }
+    DPIR_TRY(load_gn(e, wm, "out.0", ch, &net.out_gn));
+    DPIR_TRY(load_conv(e, wm, "out.2", input_ch, d->out_channels, 3, false, &net.out_conv));
+    if (ch != input_ch) return invalid("final channel count mismatch");
+
+    // time embedding (unet.py:470-478) + all FiLM projections concatenated into one [R, ted] matrix
+    const float* p0 = nullptr;
+    DPIR_TRY(wm.find("time_embed.0.weight", {ted, mc}, &p0)); DPIR_TRY(upload(e, p0, (size_t)ted * mc, &net.te_w0));
+    DPIR_TRY(wm.find("time_embed.0.bias", {ted}, &p0)); DPIR_TRY(upload(e, p0, ted, &net.te_b0));
+    DPIR_TRY(wm.find("time_embed.2.weight", {ted, ted}, &p0)); DPIR_TRY(upload(e, p0, (size_t)ted * ted, &net.te_w2));
+    DPIR_TRY(wm.find("time_embed.2.bias", {ted}, &p0)); DPIR_TRY(upload(e, p0, ted, &net.te_b2));
+    if (d->num_classes > 0) {
+        DPIR_TRY(wm.find("label_emb.weight", {d->num_classes, ted}, &p0));
+        DPIR_TRY(upload(e, p0, (size_t)d->num_classes * ted, &net.label_emb));
+    }
+    {
+        std::vector<float> fw((size_t)film_rows * ted), fb(film_rows);
+        size_t row = 0;
+        for (auto& fp : film_parts) {
+            const float *w = nullptr, *b = nullptr;
+            DPIR_TRY(wm.find(fp.first + ".weight", {2 * fp.second, ted}, &w));
+            DPIR_TRY(wm.find(fp.first + ".bias", {2 * fp.second}, &b));
+            memcpy(&fw[row * ted], w, (size_t)2 * fp.second * ted * sizeof(float));
+            memcpy(&fb[row], b, (size_t)2 * fp.second * sizeof(float));
+            row += 2 * fp.second;
+        }
+        DPIR_TRY(upload(e, fw.data(), fw.size(), &net.film_w));
+        DPIR_TRY(upload(e, fb.data(), fb.size(), &net.film_b));
+        net.film_rows = film_rows;
+    }
+    {   // nn.py:114-116, correctly rounded on the host
+        int half = mc / 2;
+        std::vector<float> fr(half);
+        for (int i = 0; i < half; ++i) {
+            float arg = -(float)log(10000.0) * (float)i / (float)half;   // float32 arithmetic as in torch
+            fr[i] = (float)exp((double)arg);
+        }
+        DPIR_TRY(upload(e, fr.data(), half, &net.freqs));
+    }
+    net.loaded = true;
+    return Status{};
+}
+
+// ------------------------------------------------------------------------------------------ forward
+namespace {
+struct Act {   // an activation tensor (possibly a virtual concat of two)
+    const float* a = nullptr; int ca = 0;
+    const float* b = nullptr; int cb = 0;
+    int H = 0, W = 0;
+    int C() const { return ca + cb; }
+};
+
+struct Fwd {
+    dpir_engine* e;
+    hipStream_t s;
+    Workspace& ws;
+    int B;
+    const float* film;     // [B, film_rows]
+    int film_rows;
+
+    Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
+        ConvArgs a;
+        a.src.a = in.a; a.src.ca = in.ca; a.src.b = in.b; a.src.cb = in.cb; a.src.Hs = in.H; a.src.Ws = in.W;
+        a.src.mode = mode; a.src.prm = prm;
+        a.w = cw.w; a.bias = cw.bias; a.out = out; a.res = res; a.res_mode = res_mode;
+        a.B = B; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutP = cw.coutp; a.H = Ho; a.W = Wo; a.ks = cw.ks;
+        ProfScope ps(&e->prof, cw.ks == 3 ? PC_CONV3 : PC_CONV1);
+        return launch_conv(s, a);
+    }
+    Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out) {
+        float2* stats = nullptr; float4* prm = nullptr;
+        DPIR_TRY(ws.getT(tag + "#stats", (size_t)B * 32, &stats));
+        DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * g.c, &prm));
+        {
+            ProfScope ps(&e->prof, PC_GN);
+            DPIR_TRY(launch_gn_stats(s, CatSrc{in.a, in.ca, in.b, in.cb}, B, in.H * in.W, stats));
+        }
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_gn_prm(s, stats, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
+        *prm_out = prm;
+        return Status{};
+    }
+    void tap(const std::string& name, const float* p, size_t numel) {
+        if (e->collect_taps) e->taps[name] = TapInfo{p, numel};
+    }
+
+    Status resblock(const ResW& r, const Act& in, Act* out) {
+        if (in.C() != r.cin) return invalid("resblock " + r.name + ": input channels mismatch");
+        int Ho = r.mode == 1 ? in.H * 2 : (r.mode == 2 ? in.H / 2 : in.H);
+        int Wo = r.mode == 1 ? in.W * 2 : (r.mode == 2 ? in.W / 2 : in.W);
+        if (r.mode == 2 && ((in.H | in.W) & 1)) return invalid("resblock " + r.name + ": odd size cannot be average-pooled");
+        size_t on = (size_t)B * r.cout * Ho * Wo;
+        float4* prm1 = nullptr; float4* prm2 = nullptr;
+        DPIR_TRY(gn(r.gn1, in, r.name + "#gn1", -1, true, &prm1));
+        float* h1 = nullptr;
+        DPIR_TRY(ws.getT(r.name + "#h1", on, &h1));
+        DPIR_TRY(conv(r.conv1, in, r.mode, prm1, nullptr, 0, h1, Ho, Wo));
+        tap(r.name + "#h1", h1, on);
+        Act h1a; h1a.a = h1; h1a.ca = r.cout; h1a.H = Ho; h1a.W = Wo;
+        DPIR_TRY(gn(r.gn2, h1a, r.name + "#gn2", r.film_off, true, &prm2));
+        const float* res = nullptr; int res_mode = 0;
+        if (r.has_skip) {
+            float* sk = nullptr;
+            DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
+            DPIR_TRY(conv(r.skip, in, 0, nullptr, nullptr, 0, sk, Ho, Wo));
+            res = sk;
+        } else {
+            if (in.b) return invalid("resblock " + r.name + ": identity skip on a concatenated input");
+            res = in.a; res_mode = r.mode;
+        }
+        float* o = nullptr;
+        DPIR_TRY(ws.getT(r.name + "#out", on, &o));
+        DPIR_TRY(conv(r.conv2, h1a, 0, prm2, res, res_mode, o, Ho, Wo));
+        tap(r.name, o, on);
+        out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
+        return Status{};
+    }
+
+    Status attention(const AttnW& aw, const Act& in, Act* out) {
+        if (in.b || in.ca != aw.c) return invalid("attention " + aw.name + ": bad input");
+        int T = in.H * in.W;
+        float4* prm = nullptr;
+        DPIR_TRY(gn(aw.norm, in, aw.name + "#norm", -1, false, &prm));
+        float *qkv = nullptr, *att = nullptr, *o = nullptr;
+        DPIR_TRY(ws.getT(aw.name + "#qkv", (size_t)B * 3 * aw.c * T, &qkv));
+        DPIR_TRY(ws.getT(aw.name + "#att", (size_t)B * aw.c * T, &att));
+        DPIR_TRY(ws.getT(aw.name + "#out", (size_t)B * aw.c * T, &o));
+        DPIR_TRY(conv(aw.qkv, in, 0, prm, nullptr, 0, qkv, in.H, in.W));
+        {
+            ProfScope ps(&e->prof, PC_ATTN);
+            DPIR_TRY(launch_attention(s, qkv, att, B, aw.c, T, 64));
+        }
+        Act aa; aa.a = att; aa.ca = aw.c; aa.H = in.H; aa.W = in.W;
+        DPIR_TRY(conv(aw.proj, aa, 0, nullptr, in.a, 0, o, in.H, in.W));
+        tap(aw.name + "#qkv", qkv, (size_t)B * 3 * aw.c * T);
+        tap(aw.name + "#att", att, (size_t)B * aw.c * T);
+        tap(aw.name, o, (size_t)B * aw.c * T);
+        out->a = o; out->ca = aw.c; out->b = nullptr; out->cb = 0; out->H = in.H; out->W = in.W;
+        return Status{};
+    }
+
+    Status run_block(const UNet& net, const Block& blk, Act in, Act* out) {
+        Act cur = in;
+        for (const Layer& l : blk) {
+            Act nxt;
+            if (l.kind == 1) DPIR_TRY(resblock(net.res[l.idx], cur, &nxt));
+            else if (l.kind == 2) DPIR_TRY(attention(net.attn[l.idx], cur, &nxt));
+            else return invalid("unexpected layer kind");
+            cur = nxt;
+        }
+        *out = cur;
+        return Status{};
+    }
+};
+}  // namespace
+
+Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W) {
+    UNet& net = e->net;
+    if (!net.loaded) return Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"};
+    if ((net.desc.num_classes > 0) != (y_dev != nullptr))
+        return invalid("must specify y if and only if the model is class-conditional");   // unet.py:643-645
+    if (B <= 0 || H <= 0 || W <= 0) return invalid("bad batch / image size");
+    Workspace& ws = e->ws;
+    hipStream_t s = e->stream;
+    ProfScope whole(&e->prof, PC_UNET);
+    const int mc = net.desc.model_channels, ted = 4 * mc;
+    float *tmp = nullptr, *semb = nullptr, *film = nullptr;
+    DPIR_TRY(ws.getT("emb#tmp", (size_t)B * (mc + ted), &tmp));
+    DPIR_TRY(ws.getT("emb#semb", (size_t)B * ted, &semb));
+    DPIR_TRY(ws.getT("emb#film", (size_t)B * net.film_rows, &film));
+    {
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_time_embed(s, t_dev, y_dev, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, net.label_emb, B, mc, tmp, semb));
+        DPIR_TRY(launch_rows_gemv(s, net.film_w, net.film_b, semb, B, net.film_rows, ted, film));
+    }
+    Fwd f{e, s, ws, B, film, net.film_rows};
+    if (e->collect_taps) e->taps.clear();
+
+    std::vector<Act> hs;
+    Act h;
+    {
+        float* o = nullptr;
+        size_t on = (size_t)B * net.conv_in.cout * H * W;
+        DPIR_TRY(ws.getT("input_blocks.0.0#out", on, &o));
+        Act xin; xin.a = x; xin.ca = 3; xin.H = H; xin.W = W;
+        DPIR_TRY(f.conv(net.conv_in, xin, 0, nullptr, nullptr, 0, o, H, W));
+        f.tap("input_blocks.0.0", o, on);
+        h.a = o; h.ca = net.conv_in.cout; h.H = H; h.W = W;
+        hs.push_back(h);
+    }
+    for (size_t i = 1; i < net.in_blocks.size(); ++i) {
+        Act o;
+        DPIR_TRY(f.run_block(net, net.in_blocks[i], h, &o));
+        h = o;
+        hs.push_back(h);
+    }
+    {
+        Act o;
+        DPIR_TRY(f.run_block(net, net.mid, h, &o));
+        h = o;
+    }
+    for (size_t i = 0; i < net.out_blocks.size(); ++i) {
+        Act skip = hs.back(); hs.pop_back();
+        if (skip.H != h.H || skip.W != h.W) return invalid("skip connection size mismatch (image size not divisible by the UNet stride)");
+        Act cat; cat.a = h.a; cat.ca = h.ca; cat.b = skip.a; cat.cb = skip.ca; cat.H = h.H; cat.W = h.W;   // th.cat([h, hs.pop()], 1)
+        Act o;
+        DPIR_TRY(f.run_block(net, net.out_blocks[i], cat, &o));
+        h = o;
+    }
+    float4* prm = nullptr;
+    DPIR_TRY(f.gn(net.out_gn, h, "out#gn", -1, true, &prm));
+    DPIR_TRY(f.conv(net.out_conv, h, 0, prm, nullptr, 0, out, H, W));
+    f.tap("out", out, (size_t)B * net.desc.out_channels * H * W);
+    return Status{};
+}
+
+double unet_flops(const UNet& net, int H, int W) {
+    if (!net.loaded) return 0.0;
+    const double mc = net.desc.model_channels, ted = 4 * mc;
+    double fl = 2 * (mc * ted + ted * ted);
+    double h = H, w = W;
+    auto res = [&](const ResW& r) {
+        if (r.mode == 1) { h *= 2; w *= 2; } else if (r.mode == 2) { h /= 2; w /= 2; }
+        fl += 2.0 * 9 * r.cin * r.cout * h * w + 2.0 * 9 * r.cout * r.cout * h * w + 2.0 * ted * 2 * r.cout;
+        if (r.has_skip) fl += 2.0 * r.cin * r.cout * h * w;
+    };
+    auto att = [&](const AttnW& a) {
+        double T = h * w, c = a.c;
+        fl += 2 * c * 3 * c * T + 2 * c * c * T + 2 * 2 * T * T * c;
+    };
+    auto blk = [&](const Block& b) {
+        for (const Layer& l : b) {
+            if (l.kind == 0) fl += 2.0 * 9 * 3 * net.conv_in.cout * h * w;
+            else if (l.kind == 1) res(net.res[l.idx]);
+            else att(net.attn[l.idx]);
+        }
+    };
+    for (auto& b : net.in_blocks) blk(b);
+    blk(net.mid);
+    for (auto& b : net.out_blocks) blk(b);
+    fl += 2.0 * 9 * net.out_conv.cin * net.out_conv.cout * H * W;
+    return fl;
+}
+
+}  // namespace dpir

@@ -1,0 +1,187 @@
+"""Python handle of the HIP engine: device arrays and thin wrappers over the C ABI.
+
+Host language note: the reference is 100 % Python, so the host side above the C ABI is Python and
+mirrors the reference's call signatures (see utils_model.py / utils_sisr.py in this package).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+class EngineError(RuntimeError):
+    pass
+
+
+def _ptr(a) -> Optional[int]:
+    """Raw device address of a DeviceArray / torch cuda tensor / int / None."""
+    if a is None:
+        return None
+    if isinstance(a, DeviceArray):
+        return a.ptr
+    if isinstance(a, int):
+        return a
+    if hasattr(a, "data_ptr"):        # torch.Tensor (plumbing only)
+        if not a.is_cuda or not a.is_contiguous():
+            raise EngineError("torch tensors passed to the engine must be contiguous CUDA/HIP tensors")
+        return a.data_ptr()
+    raise TypeError(f"cannot take a device pointer of {type(a)}")
+
+
+class DeviceArray:
+    """A contiguous device buffer owned by an Engine (dpir_malloc)."""
+
+    def __init__(self, engine: "Engine", shape: Sequence[int], dtype=np.float32):
+        self.engine = engine
+        self.shape = tuple(int(s) for s in shape)
+        self.dtype = np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape, dtype=np.int64)) * self.dtype.itemsize
+        p = C.c_void_p()
+        engine._check(engine.lib.dpir_malloc(engine.h, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+
+    def __del__(self):
+        try:
+            if self.ptr and self.engine.h:
+                self.engine.lib.dpir_free(self.engine.h, self.ptr)
+        except Exception:
+            pass
+        self.ptr = None
+
+    @property
+    def size(self):
+        return int(np.prod(self.shape, dtype=np.int64))
+
+    def copy_from(self, host) -> "DeviceArray":
+        a = np.ascontiguousarray(host, dtype=self.dtype)
+        if a.shape != self.shape:
+            raise EngineError(f"shape mismatch: {a.shape} vs {self.shape}")
+        self.engine._check(self.engine.lib.dpir_h2d(self.engine.h, self.ptr, a.ctypes.data, self.nbytes))
+        return self
+
+    def numpy(self) -> np.ndarray:
+        out = np.empty(self.shape, self.dtype)
+        self.engine._check(self.engine.lib.dpir_d2h(self.engine.h, out.ctypes.data, self.ptr, self.nbytes))
+        return out
+
+    def clone(self) -> "DeviceArray":
+        o = DeviceArray(self.engine, self.shape, self.dtype)
+        self.engine._check(self.engine.lib.dpir_d2d(self.engine.h, o.ptr, self.ptr, self.nbytes))
+        return o
+
+
+class Engine:
+    """One engine per GPU.  Raises EngineError / EngineLibraryError if the HIP path is unavailable."""
+
+    def __init__(self, device: int = 0):
+        self.lib = _lib.load()
+        h = C.c_void_p()
+        rc = self.lib.dpir_create(int(device), C.byref(h))
+        if rc != 0 or not h.value:
+            raise EngineError(f"dpir_create(device={device}) failed with status {rc}: no usable gfx950 GPU "
+                              f"(the engine has no CPU fallback)")
+        self.h = h
+        self.device = device
+        self._keep = []
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.dpir_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc != 0:
+            msg = self.lib.dpir_last_error(self.h)
+            raise EngineError(f"engine error {rc}: {msg.decode() if msg else ''}")
+
+    # ---- memory
+    def empty(self, shape, dtype=np.float32) -> DeviceArray:
+        return DeviceArray(self, shape, dtype)
+
+    def to_device(self, host, dtype=None) -> DeviceArray:
+        a = np.ascontiguousarray(host if dtype is None else np.asarray(host, dtype=dtype))
+        return DeviceArray(self, a.shape, a.dtype).copy_from(a)
+
+    def sync(self):
+        self._check(self.lib.dpir_sync(self.h))
+
+    # ---- UNet
+    def load_unet(self, desc: "_lib.UNetDesc", state_dict: Dict[str, np.ndarray]):
+        n = len(state_dict)
+        arr = (_lib.Tensor * n)()
+        keep = []
+        for i, (k, v) in enumerate(state_dict.items()):
+            if hasattr(v, "detach"):           # torch tensor from torch.load (checkpoint loading only)
+                v = v.detach().cpu().numpy()
+            a = np.ascontiguousarray(v, dtype=np.float32)
+            keep.append(a)
+            arr[i].name = k.encode()
+            arr[i].data = a.ctypes.data
+            arr[i].ndim = a.ndim
+            for d in range(a.ndim):
+                arr[i].shape[d] = a.shape[d]
+        self._check(self.lib.dpir_load_unet(self.h, C.byref(desc), arr, n))
+
+    def unet_forward(self, x, t, y=None, out=None):
+        B, _, H, W = x.shape
+        t = np.ascontiguousarray(t, dtype=np.int64)
+        yv = None if y is None else np.ascontiguousarray(y, dtype=np.int64)
+        oc = self.out_channels
+        if out is None:
+            out = self.empty((B, oc, H, W))
+        self._check(self.lib.dpir_unet_forward(self.h, _ptr(x), t.ctypes.data, None if yv is None else yv.ctypes.data,
+                                               _ptr(out), B, H, W))
+        return out
+
+    out_channels = 6
+
+    def model_fn_xstart(self, x, t: int, c1: float, c2: float, y=None, out=None):
+        B, _, H, W = x.shape
+        yv = None if y is None else np.ascontiguousarray(y, dtype=np.int64)
+        if out is None:
+            out = self.empty((B, 3, H, W))
+        self._check(self.lib.dpir_model_fn_xstart(self.h, _ptr(x), int(t), float(c1), float(c2),
+                                                  None if yv is None else yv.ctypes.data, _ptr(out), B, H, W))
+        return out
+
+    def read_tap(self, name: str) -> np.ndarray:
+        n = C.c_size_t()
+        self._check(self.lib.dpir_unet_read_tap(self.h, name.encode(), None, 0, C.byref(n)))
+        out = np.empty(n.value, np.float32)
+        self._check(self.lib.dpir_unet_read_tap(self.h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
+        return out
+
+    def unet_flops(self, H, W) -> float:
+        return float(self.lib.dpir_unet_flops(self.h, H, W))
+
+    # ---- profiling
+    def prof_enable(self, on=True):
+        self._check(self.lib.dpir_prof_enable(self.h, 1 if on else 0))
+
+    def prof_reset(self):
+        self._check(self.lib.dpir_prof_reset(self.h))
+
+    def prof_read(self):
+        ms = (C.c_double * _lib.PROF_CLASSES)()
+        cnt = (C.c_int64 * _lib.PROF_CLASSES)()
+        self._check(self.lib.dpir_prof_read(self.h, ms, cnt))
+        return {_lib.PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(_lib.PROF_CLASSES)}
+
+
+_default: Dict[int, Engine] = {}
+
+
+def default_engine(device: int = 0) -> Engine:
+    if device not in _default:
+        _default[device] = Engine(device)
+    return _default[device]

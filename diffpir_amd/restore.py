@@ -1,0 +1,217 @@
+"""One batch of the DiffPIR restoration loop (main_ddpir.py:259-470) on the HIP engine.
+
+Two entry points with identical results:
+  * restore_batch          -- the fast path: host builds the per-step scalar table once, then ONE call
+                              into dpir_run_loop (optionally a cached hipGraph) does init -> N x
+                              (UNet -> prox -> re-noise) -> finalize without returning to Python.
+  * restore_batch_stepwise -- the reference's loop body, line for line, calling the drop-in plugs
+                              (utils_model.model_fn, utils_sisr.pre_calculate/data_solution, ...).
+                              Exists to show (and test) that the reference loop runs unmodified
+                              against the engine's operator surface.
+Noise: noise_source="host" draws N(0,1) on the host in the reference's order (SURVEY.md 8 a-R: init,
+then per step p_sample / n1 / n2) through `noise_fn(shape) -> np.ndarray` and uploads what the loop
+consumes; noise_source="device" uses the engine's Philox stream keyed by (seed, global image index,
+draw index), which makes results independent of how a batch is sharded across GPUs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+from typing import Callable, Optional
+
+import numpy as np
+
+from . import _lib
+from .engine import Engine, DeviceArray, _ptr, EngineError
+from .schedule import build_steps
+
+TASKS = {"deblur": 0, "sr_blur": 1, "inpaint": 2, "sr_cubic": 3}
+
+
+@dataclass
+class LoopConfig:
+    """The YAML keys that reach the loop (configs/*.yaml; derived fields main_ddpir.py:138-158)."""
+    task: str = "deblur"               # deblur | sr | inpaint
+    iter_num: int = 100
+    noise_level_img: float = 12.75 / 255.0     # already /255 (main_ddpir.py:138)
+    lambda_: float = 7.0
+    zeta: float = 0.3
+    eta: float = 0.0
+    guidance_scale: float = 1.0
+    sf: int = 1
+    sr_mode: str = "blur"
+    inIter: int = 1
+    gamma: float = 0.01
+    skip_type: str = "quad"
+    num_train_timesteps: int = 1000
+    beta_start: float = 0.0001
+    beta_end: float = 0.02
+    generate_mode: str = "DiffPIR"
+    model_output_type: str = "pred_xstart"
+    sub_1_analytic: bool = True
+    ddim_sample: bool = False
+    iter_num_U: int = 1
+
+    @property
+    def sigma(self):
+        return max(0.001, self.noise_level_img)
+
+    def engine_task(self) -> int:
+        if self.task == "deblur":
+            return TASKS["deblur"]
+        if self.task == "inpaint":
+            return TASKS["inpaint"]
+        if self.task == "sr":
+            return TASKS["sr_blur"] if self.sr_mode == "blur" else TASKS["sr_cubic"]
+        raise ValueError(f"unknown task {self.task}")
+
+    def check_supported(self):
+        if self.generate_mode != "DiffPIR" or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
+                or self.ddim_sample or self.iter_num_U != 1:
+            raise NotImplementedError("only generate_mode=DiffPIR, model_output_type=pred_xstart, sub_1_analytic=true, "
+                                      "ddim_sample=false, iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
+
+
+def _steps(cfg: LoopConfig):
+    return build_steps(iter_num=cfg.iter_num, sigma=cfg.sigma, lambda_=cfg.lambda_, zeta=cfg.zeta, eta=cfg.eta,
+                       skip_type=cfg.skip_type, T=cfg.num_train_timesteps, beta_start=cfg.beta_start, beta_end=cfg.beta_end)
+
+
+def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool):
+    """Consume noise_fn in the reference's order; keep only what the loop uses."""
+    init = np.asarray(noise_fn(shape), dtype=np.float32)
+    n_re = sum(1 for s in steps if not s["last"])
+    n1 = np.empty((n_re,) + tuple(shape), np.float32) if need_n1 else None
+    n2 = np.empty((n_re,) + tuple(shape), np.float32)
+    j = 0
+    for s in steps:
+        noise_fn(shape)                                   # p_sample's randn_like (gaussian_diffusion.py:430), unused
+        if not s["last"]:
+            a = noise_fn(shape)
+            if need_n1:
+                n1[j] = a
+            n2[j] = noise_fn(shape)
+            j += 1
+    return init, n1, n2
+
+
+def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=None, noise_source="device",
+                  noise_fn: Optional[Callable] = None, seed: int = 0, image_offset: int = 0, use_graph: bool = False,
+                  skip_dead_final_eval: bool = False, out_f32=None, out_u8=None, return_u8: bool = False, _cache: dict = None):
+    """y: [B,3,h,w] in [0,1]; k: [B,1,kh,kw]; mask: uint8 [B,3,H,W] -- device arrays (or numpy, uploaded).
+    Returns a DeviceArray [B,3,H,W] = x_0 in [0,1] (un-clamped, main_ddpir.py:470), and the u8 NHWC
+    array as well when return_u8."""
+    cfg.check_supported()
+    dt, steps, arr = _steps(cfg)
+    keep = []
+
+    def dev(a, dtype):
+        if a is None:
+            return None
+        if isinstance(a, np.ndarray):
+            d = engine.to_device(a, dtype)
+            keep.append(d)
+            return d
+        return a
+    y = dev(y, np.float32); k = dev(k, np.float32); mask = dev(mask, np.uint8)
+    B, _, h, w = y.shape
+    H, W = h * cfg.sf, w * cfg.sf
+    d = _lib.LoopDesc()
+    d.task = cfg.engine_task()
+    d.B, d.H, d.W, d.sf = B, H, W, cfg.sf
+    if k is not None:
+        d.kh, d.kw = k.shape[2], k.shape[3]
+    d.in_iter, d.gamma, d.guidance = cfg.inIter, cfg.gamma, cfg.guidance_scale
+    t_start = cfg.num_train_timesteps - 1
+    d.sa_start, d.s1m_start = float(dt.sqrt_ac[t_start]), float(dt.sqrt_1m_ac[t_start])
+    d.y_dev, d.k_dev, d.mask_dev = _ptr(y), _ptr(k), _ptr(mask)
+    lab = None
+    if labels is not None:
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        d.labels_host = lab.ctypes.data
+    if noise_source == "host":
+        if noise_fn is None:
+            raise EngineError("noise_source='host' needs noise_fn")
+        init, n1, n2 = draw_host_noise(noise_fn, steps, (B, 3, H, W), cfg.eta != 0)
+        di, d2 = engine.to_device(init), engine.to_device(n2)
+        keep += [di, d2]
+        d.noise_init_dev, d.noise_n2_dev = di.ptr, d2.ptr
+        if n1 is not None:
+            d1 = engine.to_device(n1)
+            keep.append(d1)
+            d.noise_n1_dev = d1.ptr
+    elif noise_source != "device":
+        raise ValueError("noise_source must be 'host' or 'device'")
+    d.seed, d.image_offset = seed, image_offset
+    d.use_graph, d.skip_dead_final_eval = int(use_graph), int(skip_dead_final_eval)
+    if out_f32 is None:
+        out_f32 = engine.empty((B, 3, H, W))
+    if out_u8 is None and return_u8:
+        out_u8 = engine.empty((B, H, W, 3), np.uint8)
+    engine._check(engine.lib.dpir_run_loop(engine.h, C.byref(d), arr, len(steps), _ptr(out_f32), _ptr(out_u8)))
+    if _cache is not None:
+        _cache["keep"] = keep
+    else:
+        engine.sync()
+    return (out_f32, out_u8) if return_u8 else out_f32
+
+
+def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = None, labels=None):
+    """The reference's loop body (main_ddpir.py:291-470) against the drop-in plugs, host-fed noise."""
+    from . import utils_model, utils_sisr as sr
+    eng: Engine = model.engine
+    cfg.check_supported()
+    dt, steps, arr = _steps(cfg)
+    B, _, h, w = y.shape
+    H, W = h * cfg.sf, w * cfg.sf
+    shape = (B, 3, H, W)
+    lib, hnd = eng.lib, eng.h
+    x = eng.empty(shape)
+    # (3) initialize x (main_ddpir.py:293-315)
+    if cfg.task == "sr":
+        src = eng.empty(shape)
+        eng._check(lib.dpir_bicubic_up(hnd, _ptr(y), src.ptr, cfg.sf, B, h, w))
+        xs = src.numpy()
+    elif cfg.task == "deblur":
+        xs = y.numpy()
+    else:
+        xs = y.numpy() * mask.numpy().astype(np.float32)
+    t_start = cfg.num_train_timesteps - 1
+    n0 = np.asarray(noise_fn(shape), np.float32)
+    x.copy_from(dt.sqrt_ac[t_start] * (np.float32(2) * xs - np.float32(1)) + dt.sqrt_1m_ac[t_start] * n0)
+    if cfg.task in ("sr", "deblur") and not (cfg.task == "sr" and cfg.sr_mode == "cubic"):
+        FB, FBC, F2B, FBFy = sr.pre_calculate(y, k, cfg.sf, engine=eng)
+    kwargs = {} if labels is None else {"y": labels}
+    for i, st in enumerate(steps):
+        curr_sigma = dt.reduced[st["t"]]
+        x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type="pred_xstart", model_diffusion=model,
+                                  diffusion=diffusion, ddim_sample=False, alphas_cumprod=dt.alphas_cumprod, **kwargs)
+        noise_fn(shape)                                     # p_sample's draw
+        if not st["last"]:
+            tau = np.float32(st["tau"])
+            if cfg.task == "inpaint":
+                eng._check(lib.dpir_prox_mask(hnd, x0.ptr, _ptr(y), _ptr(mask), float(tau), cfg.guidance_scale, B, H, W))
+            elif cfg.task == "deblur" or cfg.sr_mode == "blur":
+                x0_p = eng.empty(shape)
+                eng._check(lib.dpir_finalize(hnd, x0.ptr, x0_p.ptr, None, B, H, W))          # x0/2+.5
+                x0_p = sr.data_solution(x0_p, FB, FBC, F2B, FBFy, tau, cfg.sf)
+                a, b = x0.numpy(), x0_p.numpy() * np.float32(2) - np.float32(1)
+                x0.copy_from(a + np.float32(cfg.guidance_scale) * (b - a))
+            else:
+                eng._check(lib.dpir_prox_ibp(hnd, x0.ptr, _ptr(y), float(tau), cfg.gamma, cfg.inIter, cfg.sf, B, H, W))
+            n1 = eng.to_device(np.asarray(noise_fn(shape), np.float32))
+            n2 = eng.to_device(np.asarray(noise_fn(shape), np.float32))
+            eng._check(lib.dpir_renoise(hnd, x.ptr, x0.ptr, C.byref(arr[i]), n1.ptr, n2.ptr, B, H, W))
+    out = eng.empty(shape)
+    eng._check(lib.dpir_finalize(hnd, x.ptr, out.ptr, None, B, H, W))
+    eng.sync()
+    return out
+
+
+def psnr_batch(a: np.ndarray, b: np.ndarray, max_pixel=2.0, eps=1e-10) -> float:
+    """utils/utils_image.py:601-610 on numpy arrays in [-1,1]."""
+    mse = np.mean((a.astype(np.float32) - b.astype(np.float32)) ** 2, axis=(1, 2, 3), dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        v = np.where(mse == 0, np.inf, 20 * np.log10(max_pixel / np.sqrt(mse + np.float32(eps))))
+    v = np.where(np.isnan(v), 0.0, v)
+    return float(np.mean(v))

@@ -1,0 +1,210 @@
+/*
+ * diffpir_engine.h -- C ABI of the MI355X-native DiffPIR sampling engine (libdiffpir_hip.so).
+ *
+ * The reference (yuanzhi-zhu/DiffPIR) has no FFI: its "plugin surface" is three Python call
+ * signatures used by main_ddpir.py's restoration loop.  Each entry point
+ * below names the reference interface it replaces (paths relative to the reference root).
+ * The Python shims in diffpir_amd/ (utils_model.model_fn, utils_sisr.pre_calculate /
+ * data_solution, ...) mirror those signatures and call straight into these symbols via ctypes;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *   - every function returns 0 (DPIR_OK) or a negative dpir_status; nothing throws or aborts
+ *     across the ABI; dpir_last_error() gives the message for the last failure on that engine.
+ *   - "dev" pointers are raw device addresses (engine-allocated with dpir_malloc, or any other
+ *     HIP allocation such as torch.Tensor.data_ptr()); "host" pointers are plain host memory.
+ *   - tensors are fp32, NCHW, contiguous; images are in [-1,1] inside the loop and y in [0,1],
+ *     exactly as in main_ddpir.py.  Masks are uint8 {0,1} (bit-exact integer semantics).
+ *   - all work is enqueued on ONE engine-owned HIP stream; calls are asynchronous unless noted
+ *     (dpir_sync, D2H copies).  One engine per device; an engine is not thread-safe, independent
+ *     engines are.
+ */
+#ifndef DIFFPIR_ENGINE_H
+#define DIFFPIR_ENGINE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPIR_ABI_VERSION 1
+
+typedef enum dpir_status {
+    DPIR_OK = 0,
+    DPIR_ERR_INVALID = -1,   /* bad argument / shape / missing weight */
+    DPIR_ERR_HIP = -2,       /* a HIP runtime call failed */
+    DPIR_ERR_NOMEM = -3,
+    DPIR_ERR_STATE = -4,     /* e.g. forward before load_unet */
+    DPIR_ERR_UNSUPPORTED = -5
+} dpir_status;
+
+typedef struct dpir_engine dpir_engine;   /* opaque */
+typedef struct dpir_prox dpir_prox;       /* opaque: FB / F2B / FBFy spectra of one batch */
+
+/* ---- lifecycle -------------------------------------------------------------------------- */
+int dpir_version(void);
+/* device = HIP ordinal.  Fails with DPIR_ERR_HIP when no gfx950 device is visible. */
+int dpir_create(int device, dpir_engine** out);
+void dpir_destroy(dpir_engine* e);
+const char* dpir_last_error(const dpir_engine* e);   /* never NULL */
+int dpir_sync(dpir_engine* e);                       /* hipStreamSynchronize on the engine stream */
+/* the engine's hipStream_t, for callers that enqueue their own work (e.g. RCCL) behind it */
+void* dpir_stream(dpir_engine* e);
+
+/* ---- device memory (plumbing) ------------------------------------------------------------ */
+int dpir_malloc(dpir_engine* e, size_t bytes, void** dev_out);
+int dpir_free(dpir_engine* e, void* dev);
+int dpir_h2d(dpir_engine* e, void* dev_dst, const void* host_src, size_t bytes);   /* async */
+int dpir_d2h(dpir_engine* e, void* host_dst, const void* dev_src, size_t bytes);   /* syncs  */
+int dpir_d2d(dpir_engine* e, void* dev_dst, const void* dev_src, size_t bytes);    /* async  */
+
+/* ---- denoiser: guided-diffusion UNet ----------------------------------------------------- */
+/* Replaces script_util.create_model(...) hyper-parameters (guided_diffusion/script_util.py:130-184
+ * as resolved by utils/utils_model.py:353-387 and main_ddpir.py:219-230). */
+typedef struct dpir_unet_desc {
+    int32_t image_size;          /* 256 / 512: only selects the default channel_mult */
+    int32_t in_channels;         /* 3 */
+    int32_t model_channels;      /* 128 (FFHQ) / 256 (ImageNet) */
+    int32_t out_channels;        /* 6 (learn_sigma) */
+    int32_t num_res_blocks;
+    int32_t num_head_channels;   /* 64 */
+    int32_t n_channel_mult;      /* 0 -> default for image_size (script_util.py:147-160) */
+    float channel_mult[8];
+    int32_t n_attention_ds;      /* downsample rates with attention, e.g. {16} */
+    int32_t attention_ds[8];
+    int32_t num_classes;         /* 0 = unconditional, else label_emb rows (class_cond) */
+} dpir_unet_desc;
+
+/* One entry of the reference state-dict (main_ddpir.py:234 torch.load -> load_state_dict). */
+typedef struct dpir_tensor {
+    const char* name;            /* reference key, e.g. "input_blocks.3.0.in_layers.2.weight" */
+    const float* data;           /* HOST pointer, fp32, contiguous, reference layout (OIHW ...) */
+    int32_t ndim;
+    int64_t shape[4];
+} dpir_tensor;
+
+/* Replaces model.load_state_dict(...).to(device) (main_ddpir.py:231-240).  Copies and repacks the
+ * weights into the engine's arena (caller keeps ownership of the host arrays).  Fails with
+ * DPIR_ERR_INVALID naming the first missing / mis-shaped key. */
+int dpir_load_unet(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* weights, int n_weights);
+
+/* Replaces UNetModel.forward (guided_diffusion/unet.py:634-663): x_dev [B,3,H,W], t_host [B] int64
+ * timesteps (host), y_host [B] int64 labels or NULL -> out_dev [B,out_channels,H,W]. */
+int dpir_unet_forward(dpir_engine* e, const float* x_dev, const int64_t* t_host, const int64_t* y_host,
+                      float* out_dev, int B, int H, int W);
+
+/* Replaces utils_model.model_fn(..., model_out_type='pred_xstart') (utils/utils_model.py:207-258)
+ * = SpacedDiffusion.p_sample -> p_mean_variance (guided_diffusion/gaussian_diffusion.py:232-333):
+ * x0 = clamp(c1*x - c2*eps, -1, 1), eps = UNet(x,t)[:, :3];  c1 = float32(sqrt(1/acp64[t])),
+ * c2 = float32(sqrt(1/acp64[t]-1)) computed by the caller from the float64 schedule. */
+int dpir_model_fn_xstart(dpir_engine* e, const float* x_dev, int t, float c1, float c2,
+                         const int64_t* y_host, float* x0_dev, int B, int H, int W);
+
+/* Optional per-layer tap for parity tests: copies the named layer's most recent output (the
+ * reference module path, e.g. "input_blocks.3.0") to host.  numel_out receives the element count. */
+int dpir_unet_read_tap(dpir_engine* e, const char* layer, float* host_dst, size_t cap_floats, size_t* numel_out);
+
+/* ---- data-fidelity operators ------------------------------------------------------------- */
+/* Replaces sr.pre_calculate(y, k, sf) (utils/utils_sisr.py:78-95): y_dev [B,3,H/sf,W/sf] in [0,1],
+ * k_dev [B,1,kh,kw]; builds FB, F2B, FBFy (full c2c spectra of size HxW) in an engine-owned object. */
+int dpir_prox_fft_precalc(dpir_engine* e, const float* y_dev, const float* k_dev, int kh, int kw,
+                          int sf, int B, int H, int W, dpir_prox** out);
+void dpir_prox_free(dpir_engine* e, dpir_prox* p);
+/* Copy spectra to host for cross-checks: which = 0 FB (complex64 [B,1,H,W]), 1 F2B (f32 [B,1,H,W]),
+ * 2 FBFy (complex64 [B,3,H,W]). */
+int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst, size_t cap_bytes);
+/* Replaces sr.data_solution(x, FB, FBC, F2B, FBFy, alpha, sf) (utils/utils_sisr.py:65-75):
+ * x_dev [B,3,H,W] in [0,1] -> out_dev (may alias x_dev). */
+int dpir_data_solution(dpir_engine* e, const dpir_prox* p, const float* x_dev, float alpha, float* out_dev);
+/* Replaces main_ddpir.py:395-400: x0 <- x0 + g*(2*data_solution(x0/2+.5, tau) - 1 - x0), in place. */
+int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0_dev, float tau, float guidance);
+/* Replaces main_ddpir.py:392-394: x0_p = (m*(2y-1)+tau*x0)/(m+tau); x0 += g*(x0_p-x0).  mask u8 [B,3,H,W]. */
+int dpir_prox_mask(dpir_engine* e, float* x0_dev, const float* y_dev, const uint8_t* mask_dev,
+                   float tau, float guidance, int B, int H, int W);
+/* Replaces Resizer(in_shape, 1/sf).forward (utils/utils_resizer.py:55-74, cubic, antialiasing):
+ * x_dev [B,3,H,W] -> out_dev [B,3,H/sf,W/sf]. */
+int dpir_resize_down(dpir_engine* e, const float* x_dev, float* out_dev, int sf, int B, int H, int W);
+/* Replaces main_ddpir.py:401-406 (sr_mode 'cubic', iterative back-projection), in place on x0:
+ * in_iter times { x0 <- 2*(z + gamma*up_nearest(y - down(z))/(1+rho)) - 1, z = x0/2+.5 }. */
+int dpir_prox_ibp(dpir_engine* e, float* x0_dev, const float* y_dev, float rho, float gamma,
+                  int in_iter, int sf, int B, int H, int W);
+/* Replaces F.interpolate(y, size=(h*sf,w*sf), mode='bicubic', align_corners=False) (main_ddpir.py:295). */
+int dpir_bicubic_up(dpir_engine* e, const float* y_dev, float* out_dev, int sf, int B, int h, int w);
+
+/* ---- loop arithmetic --------------------------------------------------------------------- */
+/* Per-step scalars (SURVEY.md 8 a-S), all computed on the host exactly as the reference does. */
+typedef struct dpir_step {
+    int32_t t;            /* t_i: UNet timestep */
+    int32_t last;         /* 1 on the final step: no prox / re-noise (main_ddpir.py:384,448) */
+    float c1, c2;         /* eps -> x0 (gaussian_diffusion.py:328-333), float64 tables cast to f32 */
+    float tau;            /* rhos[t_i] (main_ddpir.py:389) */
+    float sa_t, s1m_t;    /* sqrt_alphas_cumprod[t_i], sqrt_1m_alphas_cumprod[t_i]  (float32 tables) */
+    float sa_p;           /* sqrt_alphas_cumprod[t_im1] */
+    float k1;             /* float32(np.sqrt(1-zeta)) */
+    float q;              /* sqrt(s1m_p^2 - eta_sigma^2), float32 arithmetic as in the reference */
+    float es;             /* eta_sigma = eta * s1m_p / s1m_t * sqrt(betas[t_i])  (0 when eta == 0) */
+    float k2;             /* np.sqrt(zeta) * s1m_p */
+} dpir_step;
+
+/* Replaces main_ddpir.py:451-456 (re-noise to t_{i-1}); x_dev updated in place.
+ * x = sa_p*x0 + k1*(q*eps + es*n1) + k2*n2, eps = (x - sa_t*x0)/s1m_t.  n1_dev may be NULL when es == 0. */
+int dpir_renoise(dpir_engine* e, float* x_dev, const float* x0_dev, const dpir_step* s,
+                 const float* n1_dev, const float* n2_dev, int B, int H, int W);
+/* Replaces main_ddpir.py:470,482 + utils_image.tensor2uint_batch (utils/utils_image.py:238-242):
+ * x_dev [B,3,H,W] in [-1,1] -> out_f32 [B,3,H,W] = x/2+.5 (optional) and out_u8 [B,H,W,3] (optional). */
+int dpir_finalize(dpir_engine* e, const float* x_dev, float* out_f32_dev, uint8_t* out_u8_dev, int B, int H, int W);
+/* N(0,1) on device (Philox4x32-10 + Box-Muller) keyed by (seed, image index offset, stream id):
+ * the perf-mode replacement of torch.randn_like; parity mode feeds host noise. */
+int dpir_randn(dpir_engine* e, float* out_dev, uint64_t seed, uint64_t stream_id, int64_t image_offset,
+               int B, int C, int H, int W);
+
+/* ---- whole restoration loop (main_ddpir.py:291-470 for one batch) ------------------------- */
+typedef enum dpir_task { DPIR_TASK_DEBLUR = 0, DPIR_TASK_SR_BLUR = 1, DPIR_TASK_INPAINT = 2, DPIR_TASK_SR_CUBIC = 3 } dpir_task;
+
+typedef struct dpir_loop_desc {
+    int32_t task;                 /* dpir_task */
+    int32_t B, H, W;              /* H,W = restored (high-res) size */
+    int32_t sf;                   /* 1 for deblur / inpaint */
+    int32_t kh, kw;               /* PSF size (deblur / sr-blur) */
+    int32_t in_iter;              /* sr-cubic */
+    float gamma;                  /* sr-cubic */
+    float guidance;               /* guidance_scale */
+    float sa_start, s1m_start;    /* forward-noise coefficients at t_start (main_ddpir.py:315) */
+    const float* y_dev;           /* [B,3,H/sf,W/sf] in [0,1] */
+    const float* k_dev;           /* [B,1,kh,kw] or NULL */
+    const uint8_t* mask_dev;      /* [B,3,H,W] or NULL */
+    const int64_t* labels_host;   /* [B] or NULL (class-conditional UNet) */
+    /* host-fed noise (parity mode): init [B,3,H,W]; n1/n2 [(n_steps-1),B,3,H,W]; any may be NULL ->
+     * device Philox keyed by (seed, image_offset + b, draw index) */
+    const float* noise_init_dev;
+    const float* noise_n1_dev;
+    const float* noise_n2_dev;
+    uint64_t seed;
+    int64_t image_offset;         /* global index of image 0 of this shard (multi-GPU invariance) */
+    int32_t use_graph;            /* 1: capture one step as a hipGraph and replay it n_steps times */
+    int32_t skip_dead_final_eval; /* 1: skip the last UNet call whose output is discarded (Q2) */
+} dpir_loop_desc;
+
+/* Runs init -> n_steps x (UNet -> prox -> re-noise) -> finalize.  Outputs (either may be NULL):
+ * out_f32_dev [B,3,H,W] in [0,1] un-clamped (x_0 of main_ddpir.py:470), out_u8_dev [B,H,W,3]. */
+int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
+                  float* out_f32_dev, uint8_t* out_u8_dev);
+
+/* ---- instrumentation --------------------------------------------------------------------- */
+/* Kernel-time accounting with HIP events on the engine stream.  class ids: 0 conv3x3, 1 conv1x1,
+ * 2 groupnorm-stats, 3 attention, 4 fft-prox, 5 elementwise/other, 6 whole unet forward.
+ * dpir_prof_enable(1) makes every launch of a class bracketed by events (slow; bench only). */
+#define DPIR_PROF_CLASSES 8
+int dpir_prof_enable(dpir_engine* e, int on);
+int dpir_prof_reset(dpir_engine* e);
+/* ms_out / count_out: arrays of DPIR_PROF_CLASSES */
+int dpir_prof_read(dpir_engine* e, double* ms_out, int64_t* count_out);
+/* FLOPs (2*MAC, conv+linear+attention) of one UNet forward for one image at HxW; 0 if no model */
+double dpir_unet_flops(dpir_engine* e, int H, int W);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DIFFPIR_ENGINE_H */

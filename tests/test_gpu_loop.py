@@ -1,0 +1,117 @@
+"""-m gpu: the whole restoration loop (dpir_run_loop, eager and hipGraph) and the stepwise drop-in loop
+against the live-reference loop fixtures and the oracle; full-size PSNR parity on config C1."""
+import numpy as np
+import pytest
+import torch
+
+from diffpir_amd import restore, script_util
+from oracle import unet_oracle as uo, diffpir_oracle as do
+from tests.gpu_common import make_model, seeded_noise_fn_np, seeded_noise_fn_torch
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("deblur", dict(task="deblur", iter_num=6, lambda_=7.0, zeta=0.3), 42),
+    ("deblur_eta", dict(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3, eta=0.7), 43),
+    ("inpaint", dict(task="inpaint", iter_num=6, noise_level_img=0.0, lambda_=1.0, zeta=1.0), 44),
+    ("sr_blur", dict(task="sr", iter_num=5, lambda_=6.0, zeta=0.25, sf=4), 45),
+    ("sr_cubic", dict(task="sr", iter_num=5, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", inIter=2, gamma=0.5), 46),
+]
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import diffpir_amd
+    e = diffpir_amd.Engine(0)
+    yield e
+    e.close()
+
+
+@pytest.fixture(scope="module")
+def tiny(engine):
+    return make_model(engine, uo.tiny_hp())
+
+
+def _inputs(golden, name):
+    g, ops = golden("loops"), golden("operators")
+    k = mask = None
+    if name.startswith("deblur"):
+        y, k = g["deblur_y"], g["deblur_k"]
+    elif name == "inpaint":
+        y, mask = g["inpaint_y"], g["inpaint_mask"]
+    else:
+        y = g["sr_y"]
+        k = np.stack([ops["k_bic4"], ops["k_bic4"]])[:, None].astype(np.float32)
+    return y, k, mask, g[name + "_out"]
+
+
+@pytest.mark.parametrize("name,kw,seed", CASES)
+@pytest.mark.parametrize("graph", [False, True])
+def test_run_loop_matches_live_reference_fixture(engine, tiny, golden, name, kw, seed, graph):
+    y, k, mask, ref = _inputs(golden, name)
+    cfg = restore.LoopConfig(**kw)
+    out = restore.restore_batch(engine, cfg, y, k=k, mask=mask, noise_source="host", noise_fn=seeded_noise_fn_np(seed),
+                                use_graph=graph).numpy()
+    assert np.abs(out - ref).max() < 2e-3
+    dpsnr = abs(restore.psnr_batch(out * 2 - 1, golden("loops")["gt" if not name.startswith("sr") else "sr_gt"] * 2 - 1)
+                - restore.psnr_batch(ref * 2 - 1, golden("loops")["gt" if not name.startswith("sr") else "sr_gt"] * 2 - 1))
+    assert dpsnr < 1e-3, dpsnr
+
+
+@pytest.mark.parametrize("name,kw,seed", CASES[:1] + CASES[2:4])
+def test_stepwise_plug_loop_equals_run_loop(engine, tiny, golden, name, kw, seed):
+    model, _ = tiny
+    diffusion = script_util.create_gaussian_diffusion(steps=1000, learn_sigma=True)
+    y, k, mask, ref = _inputs(golden, name)
+    cfg = restore.LoopConfig(**kw)
+    dev = lambda a, dt=np.float32: None if a is None else engine.to_device(a, dt)
+    out = restore.restore_batch_stepwise(model, diffusion, cfg, dev(y), k=dev(k), mask=dev(mask, np.uint8),
+                                         noise_fn=seeded_noise_fn_np(seed)).numpy()
+    assert np.abs(out - ref).max() < 2e-3
+
+
+def test_graph_replay_is_bitwise_repeatable_and_device_noise_is_shard_invariant(engine, tiny, golden):
+    y, k, mask, _ = _inputs(golden, "deblur")
+    cfg = restore.LoopConfig(task="deblur", iter_num=6, lambda_=7.0, zeta=0.3)
+    yd, kd = engine.to_device(y), engine.to_device(k)
+    o = engine.empty((2, 3, 32, 32))
+    a = restore.restore_batch(engine, cfg, yd, k=kd, noise_source="device", seed=7, use_graph=True, out_f32=o).numpy()
+    b = restore.restore_batch(engine, cfg, yd, k=kd, noise_source="device", seed=7, use_graph=True, out_f32=o).numpy()
+    np.testing.assert_array_equal(a, b)
+    c = restore.restore_batch(engine, cfg, yd, k=kd, noise_source="device", seed=7, use_graph=False).numpy()
+    np.testing.assert_array_equal(a, c)
+    # image 1 restored alone with image_offset=1 equals image 1 of the batch (sharding invariance)
+    d = restore.restore_batch(engine, cfg, y[1:], k=k[1:], noise_source="device", seed=7, image_offset=1).numpy()
+    assert np.abs(d[0] - a[1]).max() < 1e-4
+    assert np.isfinite(a).all()
+
+
+def test_u8_output_and_skip_dead_final_eval(engine, tiny, golden):
+    y, k, mask, ref = _inputs(golden, "inpaint")
+    cfg = restore.LoopConfig(task="inpaint", iter_num=6, noise_level_img=0.0, lambda_=1.0, zeta=1.0)
+    f, u = restore.restore_batch(engine, cfg, y, mask=mask, noise_source="host", noise_fn=seeded_noise_fn_np(44), return_u8=True)
+    np.testing.assert_array_equal(u.numpy(), do.tensor2uint_batch(torch.from_numpy(f.numpy())))
+    g = restore.restore_batch(engine, cfg, y, mask=mask, noise_source="host", noise_fn=seeded_noise_fn_np(44),
+                              skip_dead_final_eval=True).numpy()
+    np.testing.assert_array_equal(g, f.numpy())        # Q2: the last UNet evaluation never reaches the output
+
+
+def test_config_c1_full_size_psnr_parity(engine):
+    """BASELINE config 1: FFHQ topology, 256x256 box inpainting, 20 NFE, B=1 -- engine vs oracle on identical
+    y / mask / weights / host-drawn noise: |dPSNR| <= 1e-3 dB (north-star tolerance)."""
+    from diffpir_amd import synth
+    hp = uo.ffhq_hp()
+    model, sd = make_model(engine, hp)
+    case = synth.make_case("inpaint", B=1, H=256, W=256, seed=42)
+    cfg = restore.LoopConfig(task="inpaint", iter_num=20, noise_level_img=0.0, lambda_=1.0, zeta=1.0)
+    out = restore.restore_batch(engine, cfg, case["y"], mask=case["mask"], noise_source="host",
+                                noise_fn=seeded_noise_fn_np(42)).numpy()
+    ocfg = do.LoopConfig("inpaint", 20, 0.0, 1.0, 1.0)
+    ref = do.restore(sd, hp, ocfg, torch.from_numpy(case["y"]), mask=torch.from_numpy(case["mask"]).float(),
+                     noise_fn=seeded_noise_fn_torch(42)).numpy()
+    gt = case["gt"] * 2 - 1
+    p_eng, p_ref = restore.psnr_batch(out * 2 - 1, gt), restore.psnr_batch(ref * 2 - 1, gt)
+    print(f"C1 PSNR engine {p_eng:.5f} dB, oracle {p_ref:.5f} dB, max|diff| {np.abs(out - ref).max():.3e}")
+    assert abs(p_eng - p_ref) <= 1e-3
+    # integer mask semantics: kept pixels follow the data term exactly as in the oracle
+    assert np.abs(out - ref).max() < 5e-3

@@ -1,0 +1,170 @@
+"""-m gpu: data-fidelity operators and loop arithmetic (FFT prox, masked prox, Resizer/IBP, bicubic
+init, re-noise, output quantisation, RNG) against the live-reference fixtures and the oracle."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from diffpir_amd import utils_sisr as sr, schedule, _lib
+from diffpir_amd.engine import _ptr
+from oracle import diffpir_oracle as do
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def engine():
+    import diffpir_amd
+    e = diffpir_amd.Engine(0)
+    yield e
+    e.close()
+
+
+def test_pre_calculate_and_data_solution_sf1(engine, golden):
+    g = golden("operators")
+    y, k, z = engine.to_device(g["deblur_y"]), engine.to_device(g["deblur_k"]), engine.to_device(g["deblur_z"])
+    FB, FBC, F2B, FBFy = sr.pre_calculate(y, k, 1)
+    np.testing.assert_allclose(FB.numpy(), g["deblur_FB"], atol=2e-6)
+    np.testing.assert_allclose(F2B.numpy(), g["deblur_F2B"], atol=2e-6)
+    np.testing.assert_allclose(FBFy.numpy(), g["deblur_FBFy"], atol=2e-3, rtol=1e-5)
+    for a in (1e-5, 0.02, 3.0):
+        out = sr.data_solution(z, FB, FBC, F2B, FBFy, np.float32(a), 1).numpy()
+        np.testing.assert_allclose(out, g[f"deblur_out_{a}"], atol=3e-5)
+
+
+def test_data_solution_sf4_bicubic_kernel(engine, golden):
+    g = golden("operators")
+    k4 = np.stack([g["k_bic4"], g["k_bic4"]])[:, None]
+    pre = sr.pre_calculate(engine.to_device(g["sr4_y"]), engine.to_device(k4), 4)
+    np.testing.assert_allclose(pre[0].numpy(), g["sr4_FB"], atol=2e-6)
+    np.testing.assert_allclose(pre[3].numpy(), g["sr4_FBFy"], atol=2e-4, rtol=1e-5)
+    z = engine.to_device(g["deblur_z"])
+    for a in (1e-4, 0.05, 2.0):
+        out = sr.data_solution(z, *pre, np.float32(a), 4).numpy()
+        np.testing.assert_allclose(out, g[f"sr4_out_{a}"], atol=3e-5)
+
+
+def test_data_solution_sf2_asymmetric_kernel(engine, golden):
+    g = golden("operators")
+    pre = sr.pre_calculate(engine.to_device(g["sf2_y"]), engine.to_device(g["sf2_k"]), 2)
+    np.testing.assert_allclose(pre[0].numpy(), g["sf2_FB"], atol=2e-6)
+    out = sr.data_solution(engine.to_device(g["deblur_z"]), *pre, np.float32(0.1), 2).numpy()
+    np.testing.assert_allclose(out, g["sf2_out"], atol=3e-5)
+
+
+@pytest.mark.parametrize("H,W,sf", [(256, 256, 1), (256, 256, 4), (128, 256, 2), (512, 512, 4)])
+def test_data_solution_full_size_vs_oracle_and_roundtrip(engine, H, W, sf):
+    rng = np.random.default_rng(H + sf)
+    B = 2
+    k = rng.random((B, 1, 25, 25)).astype(np.float32); k /= k.sum(axis=(2, 3), keepdims=True)
+    y = rng.random((B, 3, H // sf, W // sf)).astype(np.float32)
+    z = rng.random((B, 3, H, W)).astype(np.float32)
+    pre = sr.pre_calculate(engine.to_device(y), engine.to_device(k), sf)
+    opre = do.pre_calculate(torch.from_numpy(y), torch.from_numpy(k), sf)
+    for a in (1e-3, 0.5):
+        out = sr.data_solution(engine.to_device(z), *pre, a, sf).numpy()
+        ref = do.data_solution(torch.from_numpy(z), *opre, torch.tensor(a).float().repeat(1, 1, 1, 1), sf).numpy()
+        assert np.abs(out - ref).max() < 2e-4 * max(1.0, np.abs(ref).max())
+    # property: alpha -> infinity returns z (the prox of a negligible data term)
+    out = sr.data_solution(engine.to_device(z), *pre, 1e6, sf).numpy()
+    assert np.abs(out - z).max() < 1e-3
+
+
+def test_prox_fft_apply_matches_loop_expression(engine, golden):
+    g = golden("operators")
+    y, k = engine.to_device(g["deblur_y"]), engine.to_device(g["deblur_k"])
+    pre = sr.pre_calculate(y, k, 1)
+    x0 = (g["deblur_z"] * 2 - 1).astype(np.float32)
+    opre = do.pre_calculate(torch.from_numpy(g["deblur_y"]), torch.from_numpy(g["deblur_k"]), 1)
+    for tau, gs in ((0.02, 1.0), (0.5, 0.7)):
+        ref = do.prox_fft(torch.from_numpy(x0), opre, torch.tensor(tau).float().repeat(1, 1, 1, 1), 1, gs).numpy()
+        d = engine.to_device(x0)
+        engine._check(engine.lib.dpir_prox_fft_apply(engine.h, pre[0].spectra.handle, d.ptr, tau, gs))
+        np.testing.assert_allclose(d.numpy(), ref, atol=5e-5)
+
+
+def test_masked_prox_bit_exact_mask_semantics(engine, golden):
+    g = golden("operators")
+    rng = np.random.default_rng(0)
+    m = np.ascontiguousarray(np.broadcast_to(g["mask_box"], (2, 3, 256, 256)))
+    y = rng.random((2, 3, 256, 256)).astype(np.float32)
+    x0 = (rng.random((2, 3, 256, 256)).astype(np.float32) * 2 - 1)
+    for tau in (4e-11, 1e-4, 0.3):
+        ref = do.prox_mask(torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(m).float(),
+                           torch.tensor(tau).float().repeat(1, 1, 1, 1), 1.0).numpy()
+        d = engine.to_device(x0)
+        engine._check(engine.lib.dpir_prox_mask(engine.h, d.ptr, engine.to_device(y).ptr, engine.to_device(m).ptr, tau, 1.0, 2, 256, 256))
+        out = d.numpy()
+        np.testing.assert_allclose(out, ref, atol=1e-6)
+        # where the mask is 0 and guidance 1 the pixel is exactly x0 (tau*x0/tau); where it is 1 the data dominates
+        hole = m == 0
+        np.testing.assert_allclose(out[hole], x0[hole], atol=1e-6)
+
+
+def test_resizer_down_and_bicubic_up(engine, golden):
+    g = golden("operators")
+    x = engine.to_device(g["resizer_in"])
+    out = engine.empty((2, 3, 16, 16))
+    engine._check(engine.lib.dpir_resize_down(engine.h, x.ptr, out.ptr, 4, 2, 64, 64))
+    np.testing.assert_allclose(out.numpy(), g["resizer_out"], atol=2e-6)
+    up = engine.empty((2, 3, 64, 64))
+    engine._check(engine.lib.dpir_bicubic_up(engine.h, engine.to_device(g["resizer_out"]).ptr, up.ptr, 4, 2, 16, 16))
+    np.testing.assert_allclose(up.numpy(), g["bicubic_up"], atol=2e-6)
+    # full size 256 -> 64 against the oracle
+    rng = np.random.default_rng(1)
+    xf = rng.random((1, 3, 256, 256)).astype(np.float32)
+    of = engine.empty((1, 3, 64, 64))
+    engine._check(engine.lib.dpir_resize_down(engine.h, engine.to_device(xf).ptr, of.ptr, 4, 1, 256, 256))
+    np.testing.assert_allclose(of.numpy(), do.resizer_apply(torch.from_numpy(xf), 0.25).numpy(), atol=2e-6)
+
+
+def test_ibp_prox(engine):
+    rng = np.random.default_rng(2)
+    x0 = (rng.random((2, 3, 64, 64)).astype(np.float32) * 2 - 1)
+    y = rng.random((2, 3, 16, 16)).astype(np.float32)
+    ref = do.prox_ibp(torch.from_numpy(x0), torch.from_numpy(y), torch.tensor(0.37), 4, 0.5, 2).numpy()
+    d = engine.to_device(x0)
+    engine._check(engine.lib.dpir_prox_ibp(engine.h, d.ptr, engine.to_device(y).ptr, 0.37, 0.5, 2, 4, 2, 64, 64))
+    np.testing.assert_allclose(d.numpy(), ref, atol=3e-6)
+
+
+def test_renoise_and_finalize(engine, golden):
+    g = golden("operators")
+    rng = np.random.default_rng(3)
+    shape = (2, 3, 32, 32)
+    x, x0, n1, n2 = (rng.standard_normal(shape).astype(np.float32) for _ in range(4))
+    odt = do.DriverTables()
+    for eta, zeta in ((0.0, 0.3), (0.7, 0.3), (0.0, 1.0)):
+        dt, steps, arr = schedule.build_steps(iter_num=10, sigma=0.05, lambda_=7.0, zeta=zeta, eta=eta)
+        st = steps[4]
+        ref = do.renoise(torch.from_numpy(x), torch.from_numpy(x0), odt, st["t"], st["t_im1"], eta, zeta,
+                         torch.from_numpy(n1), torch.from_numpy(n2)).numpy()
+        d = engine.to_device(x)
+        engine._check(engine.lib.dpir_renoise(engine.h, d.ptr, engine.to_device(x0).ptr, C.byref(arr[4]),
+                                              engine.to_device(n1).ptr, engine.to_device(n2).ptr, *shape[:1], 32, 32))
+        np.testing.assert_allclose(d.numpy(), ref, atol=2e-6)
+    # output: x/2+.5 and the u8 NHWC quantisation are bit-exact against utils_image.tensor2uint_batch
+    xin = (g["u8_in"] * 2 - 1).astype(np.float32)
+    of, ou = engine.empty(xin.shape), engine.empty((2, 16, 16, 3), np.uint8)
+    engine._check(engine.lib.dpir_finalize(engine.h, engine.to_device(xin).ptr, of.ptr, ou.ptr, 2, 16, 16))
+    f = of.numpy()
+    np.testing.assert_array_equal(f, (torch.from_numpy(xin) / 2 + 0.5).numpy())
+    np.testing.assert_array_equal(ou.numpy(), do.tensor2uint_batch(torch.from_numpy(f)))
+
+
+def test_device_randn_statistics_and_shard_invariance(engine):
+    B, C_, H, W = 4, 3, 64, 64
+    a = engine.empty((B, C_, H, W))
+    engine._check(engine.lib.dpir_randn(engine.h, a.ptr, 123, 5, 0, B, C_, H, W))
+    v = a.numpy()
+    assert abs(v.mean()) < 0.02 and abs(v.std() - 1) < 0.02
+    assert abs(np.mean(v ** 4) - 3) < 0.2
+    assert np.abs(np.corrcoef(v[0].ravel(), v[1].ravel())[0, 1]) < 0.03
+    # images 2..3 drawn as their own shard (image_offset=2) are identical: results do not depend on sharding
+    b = engine.empty((2, C_, H, W))
+    engine._check(engine.lib.dpir_randn(engine.h, b.ptr, 123, 5, 2, 2, C_, H, W))
+    np.testing.assert_array_equal(b.numpy(), v[2:])
+    c = engine.empty((B, C_, H, W))
+    engine._check(engine.lib.dpir_randn(engine.h, c.ptr, 123, 6, 0, B, C_, H, W))
+    assert np.abs(np.corrcoef(c.numpy().ravel(), v.ravel())[0, 1]) < 0.01

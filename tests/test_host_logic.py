@@ -1,0 +1,105 @@
+"""CPU tests: host-side schedule tables against the live-reference fixtures and the oracle, the C-ABI
+library's exported symbols, and the fail-loudly contract (no GPU -> no fallback)."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from diffpir_amd import _lib, schedule
+from diffpir_amd.restore import LoopConfig
+from oracle import diffpir_oracle as do
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("deblur100", dict(iter_num=100, sigma=12.75 / 255, lambda_=7.0, zeta=0.3)),
+    ("inpaint20", dict(iter_num=20, sigma=0.001, lambda_=1.0, zeta=1.0)),
+    ("sr100", dict(iter_num=100, sigma=12.75 / 255, lambda_=6.0, zeta=0.25)),
+])
+def test_steps_match_reference_tables(golden, name, kw):
+    g = golden("schedule")
+    dt, steps, arr = schedule.build_steps(**kw)
+    assert [s["t"] for s in steps] == list(g[name + "_t"])
+    np.testing.assert_array_equal(np.array([s["tau"] for s in steps], np.float32), g[name + "_tau"])
+    np.testing.assert_array_equal(dt.sqrt_ac, g["drv_sqrt_ac"])
+    np.testing.assert_array_equal(dt.sqrt_1m_ac, g["drv_sqrt_1m_ac"])
+    d = schedule.DiffusionTables.make()
+    np.testing.assert_array_equal(d.sqrt_recip_ac, g["sqrt_recip_ac"])
+    assert len(arr) == len(steps) and arr[0].t == 999 and arr[len(steps) - 1].last == 1
+
+
+@pytest.mark.parametrize("eta,zeta", [(0.0, 0.3), (0.7, 0.3), (0.0, 1.0), (1.0, 0.0)])
+def test_renoise_coefficients_match_torch_expression(eta, zeta):
+    """k1,q,es,k2 must reproduce main_ddpir.py:451-456 evaluated with torch 0-dim float32 tensors."""
+    dt, steps, _ = schedule.build_steps(iter_num=12, sigma=0.05, lambda_=7.0, zeta=zeta, eta=eta)
+    odt = do.DriverTables()
+    g = torch.Generator().manual_seed(0)
+    x, x0, n1, n2 = (torch.randn(1, 3, 8, 8, generator=g) for _ in range(4))
+    for st in steps:
+        if st["last"]:
+            continue
+        ref = do.renoise(x, x0, odt, st["t"], st["t_im1"], eta, zeta, n1, n2)
+        eps = (x - np.float32(st["sa_t"]) * x0) / np.float32(st["s1m_t"])
+        mine = np.float32(st["sa_p"]) * x0 + np.float32(st["k1"]) * (np.float32(st["q"]) * eps + np.float32(st["es"]) * n1) \
+            + np.float32(st["k2"]) * n2
+        np.testing.assert_allclose(mine.numpy(), ref.numpy(), rtol=0, atol=1e-6)
+        # scalars themselves are bit-exact
+        es = eta * odt.sqrt_1m_ac[st["t_im1"]] / odt.sqrt_1m_ac[st["t"]] * torch.sqrt(odt.betas[st["t"]])
+        assert np.float32(st["es"]) == np.float32(float(es))
+        q = torch.sqrt(odt.sqrt_1m_ac[st["t_im1"]] ** 2 - es ** 2)
+        assert np.float32(st["q"]) == np.float32(float(q))
+        k2 = np.sqrt(zeta) * odt.sqrt_1m_ac[st["t_im1"]]
+        assert np.float32(st["k2"]) == np.float32(float(k2))
+
+
+def test_uniform_skip_sequence():
+    assert schedule.make_seq(1000, 10, "uniform") == [i * 100 for i in range(10)] + [999]
+    assert schedule.make_seq(1000, 20) == do.make_seq(1000, 20)
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "diffpir_engine.h")).read()
+    declared = set(re.findall(r"\b(dpir_[a-z0-9_]+)\s*\(", hdr))
+    declared -= {"dpir_status", "dpir_task"}
+    lib = _lib.load()
+    missing = [n for n in sorted(declared) if not hasattr(lib, n)]
+    assert not missing, missing
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    assert lib.dpir_version() == 1
+
+
+def test_struct_layouts_match_header():
+    import ctypes as C
+    assert C.sizeof(_lib.Step) == 48
+    assert C.sizeof(_lib.UNetDesc) == 4 * 7 + 32 + 4 + 32 + 4
+    assert _lib.LoopDesc.y_dev.offset == 48
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_engine_fails_loudly_without_gpu():
+    import diffpir_amd
+    with pytest.raises(diffpir_amd.EngineError):
+        diffpir_amd.Engine(0)
+
+
+def test_unsupported_modes_raise():
+    with pytest.raises(NotImplementedError):
+        LoopConfig(generate_mode="DPS_y0").check_supported()
+    from diffpir_amd import script_util
+    with pytest.raises(NotImplementedError):
+        script_util.create_model(256, 128, 1, learn_sigma=True, num_head_channels=64, use_scale_shift_norm=True,
+                                 resblock_updown=True, use_fp16=True)
+
+
+def test_factory_mirrors_reference_call_sequence():
+    """main_ddpir.py:219-233 runs unchanged up to the point where a GPU is needed."""
+    from diffpir_amd import utils_model, script_util
+    args = utils_model.create_argparser(dict(model_path="", num_channels=128, num_res_blocks=1, attention_resolutions="16")).parse_args([])
+    model, diffusion = script_util.create_model_and_diffusion(
+        **script_util.args_to_dict(args, script_util.model_and_diffusion_defaults().keys()))
+    assert model.desc.model_channels == 128 and model.desc.out_channels == 6
+    assert list(model.desc.attention_ds)[:1] == [16] and model.desc.n_channel_mult == 0
+    assert diffusion.sqrt_recip_alphas_cumprod.dtype == np.float64
