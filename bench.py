@@ -1,0 +1,196 @@
+"""bench.py -- restored images/sec @100 NFE, 256x256 (BASELINE.json metric) on N MI355X GPUs of one node.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE full restoration (100 NFE: init -> 100 x (UNet -> FFT prox -> re-noise) -> u8 output) of one
+batch of synthetic 256x256 inputs per GPU -- BASELINE config[1]: FFHQ topology, Gaussian deblur (61x61 PSF),
+B=16 per GPU.  Inputs (y, k) are resident in HBM before the timed region; the loop is a replayed hipGraph with
+device-side Philox noise; with N>1 the batch is sharded by image (weak scaling, no data-path collective) and the
+u8 results are all-gathered over RCCL inside the timed region.  Weights are synthetic (no checkpoint offline).
+
+The JSON line also carries
+  roofline     -- the dominant kernel (3x3 implicit-GEMM conv on fp32 MFMA): algorithmic FLOPs / launch over the
+                  HIP-event duration of every launch of that kernel class in an instrumented pass of the same
+                  workload on the engine stream, against the 157.3 TF/s fp32-MFMA peak;
+  cpu_baseline -- the oracle (CPU restatement of the reference path, torch-CPU fp32) timed on this host's cores on
+                  a bounded sample (NFE steps at B=1), extrapolated to 100 NFE.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
+    ap.add_argument("--nfe", type=int, default=100)
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--task", default="deblur", choices=["deblur", "inpaint", "sr"])
+    ap.add_argument("--model", default="ffhq", choices=["ffhq", "imagenet256"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-nfe", type=int, default=8, help="NFE steps of the CPU oracle sample (B=1)")
+    return ap.parse_args()
+
+
+def synth_weights(model_name, seed=0):
+    """Deterministic synthetic state dict in the reference key schema (product-side generator)."""
+    from diffpir_amd import weights
+    return weights.synth_state_dict(model_name, seed)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    import torch
+    import torch.distributed as dist
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import diffpir_amd
+    from diffpir_amd import restore, synth, script_util, weights
+    eng = diffpir_amd.Engine(local_rank)
+    B, H = args.batch, args.size
+    hp = weights.model_hp(args.model)
+    model = script_util.create_model(**weights.create_model_kwargs(hp), engine=eng)
+    model.load_state_dict(weights.synth_state_dict(hp, 0))
+
+    if args.task == "deblur":
+        cfg = restore.LoopConfig(task="deblur", iter_num=args.nfe, lambda_=7.0, zeta=0.3)
+        case = synth.make_case("deblur", B, H, H, seed=100 + rank, ksize=61)
+    elif args.task == "inpaint":
+        cfg = restore.LoopConfig(task="inpaint", iter_num=args.nfe, noise_level_img=0.0, lambda_=1.0, zeta=1.0)
+        case = synth.make_case("inpaint", B, H, H, seed=100 + rank)
+    else:
+        cfg = restore.LoopConfig(task="sr", iter_num=args.nfe, lambda_=6.0, zeta=0.25, sf=4)
+        case = synth.make_case("sr", B, H, H, seed=100 + rank, sf=4)
+    y = eng.to_device(case["y"])
+    k = None if case["k"] is None else eng.to_device(case["k"])
+    mask = None if case["mask"] is None else eng.to_device(case["mask"])
+    out_f32 = eng.empty((B, 3, H, H))
+    out_u8 = torch.empty((B, H, H, 3), dtype=torch.uint8, device=f"cuda:{local_rank}")     # plumbing for RCCL
+    gathered = [torch.empty_like(out_u8) for _ in range(world)] if world > 1 else None
+    keep = {}
+
+    def one_step():
+        restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source="device", seed=1234, image_offset=rank * B,
+                              use_graph=not args.no_graph, out_f32=out_f32, out_u8=out_u8, _cache=keep)
+        eng.sync()
+        if world > 1:
+            dist.all_gather(gathered, out_u8)
+
+    def fence():
+        eng.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    images = B * world * args.steps
+    value = images / elapsed
+
+    # ---- roofline of the dominant kernel, instrumented pass on rank 0 (same batch, same weights)
+    roofline = None
+    if rank == 0:
+        x = eng.to_device(np.random.default_rng(0).standard_normal((B, 3, H, H)).astype(np.float32))
+        t = np.full(B, 500)
+        o6 = eng.unet_forward(x, t)
+        eng.sync()
+        eng.prof_enable(True)
+        eng.prof_reset()
+        n_pass = 3
+        for _ in range(n_pass):
+            eng.unet_forward(x, t, out=o6)
+        eng.sync()
+        prof = eng.prof_read()
+        eng.prof_enable(False)
+        ms, cnt = prof["conv3x3"]
+        fl = eng.unet_flops(H, H, 0) * B * n_pass           # conv3x3 FLOPs of the instrumented passes
+        achieved = fl / (ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "kernel": "conv_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32)",
+                    "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+                    "launches": int(cnt), "avg_launch_ms": round(ms / max(cnt, 1), 4),
+                    "flops_per_launch_avg": fl / max(cnt, 1),
+                    "unet_forward_ms": round(prof["unet_forward"][0] / n_pass, 3),
+                    "unet_tflops": round(eng.unet_flops(H, H) * B * n_pass / (prof["unet_forward"][0] * 1e-3) / 1e12, 3),
+                    "class_ms_per_forward": {kk: round(v[0] / n_pass, 3) for kk, v in prof.items() if v[1]}}
+
+    # ---- CPU baseline: the oracle on the host cores, bounded sample, rank 0 only
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        import torch as th
+        from oracle import unet_oracle as uo, diffpir_oracle as do
+        ohp = uo.ffhq_hp() if args.model == "ffhq" else uo.imagenet256_hp()
+        sd = {kk: th.from_numpy(v) for kk, v in weights.synth_state_dict(hp, 0).items()}
+        nfe = max(2, args.cpu_nfe)
+        ocfg = do.LoopConfig(cfg.task, nfe, cfg.noise_level_img, cfg.lambda_, cfg.zeta, sf=cfg.sf)
+        g = th.Generator().manual_seed(0)
+        nf = lambda like: th.randn(like.shape, generator=g, dtype=th.float32)
+        yy = th.from_numpy(case["y"][:1])
+        kk_ = None if case["k"] is None else th.from_numpy(case["k"][:1])
+        mm = None if case["mask"] is None else th.from_numpy(case["mask"][:1]).float()
+        th.set_num_threads(os.cpu_count())
+        tc = time.perf_counter()
+        do.restore(sd, ohp, ocfg, yy, k=kk_, mask=mm, noise_fn=nf)
+        tcpu = time.perf_counter() - tc
+        per_nfe = tcpu / nfe
+        cpu = {"value": round(1.0 / (per_nfe * args.nfe), 6), "unit": "images/s", "cores": th.get_num_threads(),
+               "kind": "port", "sample": f"oracle (torch-CPU fp32 restatement of the reference loop), B=1, {nfe} NFE "
+               f"at {H}x{H} in {tcpu:.1f} s, extrapolated linearly to {args.nfe} NFE"}
+
+    if rank == 0:
+        line = {"metric": "restored images/sec @100 NFE, 256x256", "value": round(value, 4), "unit": "images/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"configs[1]: {args.model} topology {H}x{H} {args.task} "
+                                       f"({'61x61 Gaussian PSF' if args.task == 'deblur' else args.task}), {args.nfe} NFE, "
+                                       f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
+                           "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results"},
+                "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    eng.close()
+
+
+if __name__ == "__main__":
+    main()

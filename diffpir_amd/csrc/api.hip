@@ -214,6 +214,7 @@ int dpir_unet_read_tap(dpir_engine* e, const char* layer, float* host_dst, size_
 }
 
 double dpir_unet_flops(dpir_engine* e, int H, int W) { return e ? unet_flops(e->net, H, W) : 0.0; }
+double dpir_unet_flops_class(dpir_engine* e, int H, int W, int cls) { return e ? unet_flops(e->net, H, W, cls) : 0.0; }
 
 // ------------------------------------------------------------------------------------------ FFT prox
 static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, ProxState* st) {

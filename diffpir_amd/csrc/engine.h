@@ -97,5 +97,5 @@ Status unet_load(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* 
 void unet_free(dpir_engine* e);
 // t_dev/y_dev: device int32 [B]
 Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W);
-double unet_flops(const UNet& net, int H, int W);
+double unet_flops(const UNet& net, int H, int W, int cls = -1);
 }  // namespace dpir

@@ -415,23 +415,27 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     return Status{};
 }
 
-double unet_flops(const UNet& net, int H, int W) {
+// cls: -1 total, PC_CONV3 (3x3 convs), PC_CONV1 (1x1 convs incl. qkv / proj_out), PC_ATTN (attention matmuls),
+// PC_ELEM (linear layers)
+double unet_flops(const UNet& net, int H, int W, int cls) {
     if (!net.loaded) return 0.0;
     const double mc = net.desc.model_channels, ted = 4 * mc;
-    double fl = 2 * (mc * ted + ted * ted);
+    double f3 = 0, f1 = 0, fa = 0, fl = 2 * (mc * ted + ted * ted);
     double h = H, w = W;
     auto res = [&](const ResW& r) {
         if (r.mode == 1) { h *= 2; w *= 2; } else if (r.mode == 2) { h /= 2; w /= 2; }
-        fl += 2.0 * 9 * r.cin * r.cout * h * w + 2.0 * 9 * r.cout * r.cout * h * w + 2.0 * ted * 2 * r.cout;
-        if (r.has_skip) fl += 2.0 * r.cin * r.cout * h * w;
+        f3 += 2.0 * 9 * r.cin * r.cout * h * w + 2.0 * 9 * r.cout * r.cout * h * w;
+        fl += 2.0 * ted * 2 * r.cout;
+        if (r.has_skip) f1 += 2.0 * r.cin * r.cout * h * w;
     };
     auto att = [&](const AttnW& a) {
         double T = h * w, c = a.c;
-        fl += 2 * c * 3 * c * T + 2 * c * c * T + 2 * 2 * T * T * c;
+        f1 += 2 * c * 3 * c * T + 2 * c * c * T;
+        fa += 2 * 2 * T * T * c;
     };
     auto blk = [&](const Block& b) {
         for (const Layer& l : b) {
-            if (l.kind == 0) fl += 2.0 * 9 * 3 * net.conv_in.cout * h * w;
+            if (l.kind == 0) f3 += 2.0 * 9 * 3 * net.conv_in.cout * h * w;
             else if (l.kind == 1) res(net.res[l.idx]);
             else att(net.attn[l.idx]);
         }
@@ -439,8 +443,12 @@ double unet_flops(const UNet& net, int H, int W) {
     for (auto& b : net.in_blocks) blk(b);
     blk(net.mid);
     for (auto& b : net.out_blocks) blk(b);
-    fl += 2.0 * 9 * net.out_conv.cin * net.out_conv.cout * H * W;
-    return fl;
+    f3 += 2.0 * 9 * net.out_conv.cin * net.out_conv.cout * H * W;
+    if (cls == PC_CONV3) return f3;
+    if (cls == PC_CONV1) return f1;
+    if (cls == PC_ATTN) return fa;
+    if (cls == PC_ELEM) return fl;
+    return f3 + f1 + fa + fl;
 }
 
 }  // namespace dpir

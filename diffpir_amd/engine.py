@@ -161,8 +161,8 @@ class Engine:
         self._check(self.lib.dpir_unet_read_tap(self.h, name.encode(), out.ctypes.data, n.value, C.byref(n)))
         return out
 
-    def unet_flops(self, H, W) -> float:
-        return float(self.lib.dpir_unet_flops(self.h, H, W))
+    def unet_flops(self, H, W, cls: int = -1) -> float:
+        return float(self.lib.dpir_unet_flops_class(self.h, H, W, cls))
 
     # ---- profiling
     def prof_enable(self, on=True):

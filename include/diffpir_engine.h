@@ -203,6 +203,8 @@ int dpir_prof_reset(dpir_engine* e);
 int dpir_prof_read(dpir_engine* e, double* ms_out, int64_t* count_out);
 /* FLOPs (2*MAC, conv+linear+attention) of one UNet forward for one image at HxW; 0 if no model */
 double dpir_unet_flops(dpir_engine* e, int H, int W);
+/* the same split by profiling class (0 conv3x3, 1 conv1x1 incl. qkv/proj_out, 3 attention matmuls, 5 linears; -1 total) */
+double dpir_unet_flops_class(dpir_engine* e, int H, int W, int cls);
 
 #ifdef __cplusplus
 }

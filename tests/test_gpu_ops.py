@@ -28,9 +28,12 @@ def test_pre_calculate_and_data_solution_sf1(engine, golden):
     np.testing.assert_allclose(FB.numpy(), g["deblur_FB"], atol=2e-6)
     np.testing.assert_allclose(F2B.numpy(), g["deblur_F2B"], atol=2e-6)
     np.testing.assert_allclose(FBFy.numpy(), g["deblur_FBFy"], atol=2e-3, rtol=1e-5)
-    for a in (1e-5, 0.02, 3.0):
+    # the reference's closed form divides a near-cancelling difference by alpha: its fp32 rounding noise grows
+    # like eps*|FR|/alpha (measured: fp32-vs-fp64 reference 4e-2 at alpha=7e-7, 5e-4 at 1e-4, 4e-6 at 1e-2),
+    # so the tolerance follows the conditioning (DESIGN.md "fp32 noise floor")
+    for a, tol in ((1e-5, 6e-3), (0.02, 3e-5), (3.0, 3e-6)):
         out = sr.data_solution(z, FB, FBC, F2B, FBFy, np.float32(a), 1).numpy()
-        np.testing.assert_allclose(out, g[f"deblur_out_{a}"], atol=3e-5)
+        np.testing.assert_allclose(out, g[f"deblur_out_{a}"], atol=tol)
 
 
 def test_data_solution_sf4_bicubic_kernel(engine, golden):
@@ -40,9 +43,9 @@ def test_data_solution_sf4_bicubic_kernel(engine, golden):
     np.testing.assert_allclose(pre[0].numpy(), g["sr4_FB"], atol=2e-6)
     np.testing.assert_allclose(pre[3].numpy(), g["sr4_FBFy"], atol=2e-4, rtol=1e-5)
     z = engine.to_device(g["deblur_z"])
-    for a in (1e-4, 0.05, 2.0):
+    for a, tol in ((1e-4, 5e-4), (0.05, 3e-5), (2.0, 3e-6)):
         out = sr.data_solution(z, *pre, np.float32(a), 4).numpy()
-        np.testing.assert_allclose(out, g[f"sr4_out_{a}"], atol=3e-5)
+        np.testing.assert_allclose(out, g[f"sr4_out_{a}"], atol=tol)
 
 
 def test_data_solution_sf2_asymmetric_kernel(engine, golden):
@@ -93,8 +96,8 @@ def test_masked_prox_bit_exact_mask_semantics(engine, golden):
     for tau in (4e-11, 1e-4, 0.3):
         ref = do.prox_mask(torch.from_numpy(x0), torch.from_numpy(y), torch.from_numpy(m).float(),
                            torch.tensor(tau).float().repeat(1, 1, 1, 1), 1.0).numpy()
-        d = engine.to_device(x0)
-        engine._check(engine.lib.dpir_prox_mask(engine.h, d.ptr, engine.to_device(y).ptr, engine.to_device(m).ptr, tau, 1.0, 2, 256, 256))
+        d, yd, md = engine.to_device(x0), engine.to_device(y), engine.to_device(m)
+        engine._check(engine.lib.dpir_prox_mask(engine.h, d.ptr, yd.ptr, md.ptr, tau, 1.0, 2, 256, 256))
         out = d.numpy()
         np.testing.assert_allclose(out, ref, atol=1e-6)
         # where the mask is 0 and guidance 1 the pixel is exactly x0 (tau*x0/tau); where it is 1 the data dominates
@@ -108,14 +111,14 @@ def test_resizer_down_and_bicubic_up(engine, golden):
     out = engine.empty((2, 3, 16, 16))
     engine._check(engine.lib.dpir_resize_down(engine.h, x.ptr, out.ptr, 4, 2, 64, 64))
     np.testing.assert_allclose(out.numpy(), g["resizer_out"], atol=2e-6)
-    up = engine.empty((2, 3, 64, 64))
-    engine._check(engine.lib.dpir_bicubic_up(engine.h, engine.to_device(g["resizer_out"]).ptr, up.ptr, 4, 2, 16, 16))
+    up, lr = engine.empty((2, 3, 64, 64)), engine.to_device(g["resizer_out"])
+    engine._check(engine.lib.dpir_bicubic_up(engine.h, lr.ptr, up.ptr, 4, 2, 16, 16))
     np.testing.assert_allclose(up.numpy(), g["bicubic_up"], atol=2e-6)
     # full size 256 -> 64 against the oracle
     rng = np.random.default_rng(1)
     xf = rng.random((1, 3, 256, 256)).astype(np.float32)
-    of = engine.empty((1, 3, 64, 64))
-    engine._check(engine.lib.dpir_resize_down(engine.h, engine.to_device(xf).ptr, of.ptr, 4, 1, 256, 256))
+    of, xd = engine.empty((1, 3, 64, 64)), engine.to_device(xf)
+    engine._check(engine.lib.dpir_resize_down(engine.h, xd.ptr, of.ptr, 4, 1, 256, 256))
     np.testing.assert_allclose(of.numpy(), do.resizer_apply(torch.from_numpy(xf), 0.25).numpy(), atol=2e-6)
 
 
@@ -124,8 +127,8 @@ def test_ibp_prox(engine):
     x0 = (rng.random((2, 3, 64, 64)).astype(np.float32) * 2 - 1)
     y = rng.random((2, 3, 16, 16)).astype(np.float32)
     ref = do.prox_ibp(torch.from_numpy(x0), torch.from_numpy(y), torch.tensor(0.37), 4, 0.5, 2).numpy()
-    d = engine.to_device(x0)
-    engine._check(engine.lib.dpir_prox_ibp(engine.h, d.ptr, engine.to_device(y).ptr, 0.37, 0.5, 2, 4, 2, 64, 64))
+    d, yd = engine.to_device(x0), engine.to_device(y)
+    engine._check(engine.lib.dpir_prox_ibp(engine.h, d.ptr, yd.ptr, 0.37, 0.5, 2, 4, 2, 64, 64))
     np.testing.assert_allclose(d.numpy(), ref, atol=3e-6)
 
 
@@ -140,14 +143,13 @@ def test_renoise_and_finalize(engine, golden):
         st = steps[4]
         ref = do.renoise(torch.from_numpy(x), torch.from_numpy(x0), odt, st["t"], st["t_im1"], eta, zeta,
                          torch.from_numpy(n1), torch.from_numpy(n2)).numpy()
-        d = engine.to_device(x)
-        engine._check(engine.lib.dpir_renoise(engine.h, d.ptr, engine.to_device(x0).ptr, C.byref(arr[4]),
-                                              engine.to_device(n1).ptr, engine.to_device(n2).ptr, *shape[:1], 32, 32))
+        d, x0d, n1d, n2d = (engine.to_device(v) for v in (x, x0, n1, n2))
+        engine._check(engine.lib.dpir_renoise(engine.h, d.ptr, x0d.ptr, C.byref(arr[4]), n1d.ptr, n2d.ptr, *shape[:1], 32, 32))
         np.testing.assert_allclose(d.numpy(), ref, atol=2e-6)
     # output: x/2+.5 and the u8 NHWC quantisation are bit-exact against utils_image.tensor2uint_batch
     xin = (g["u8_in"] * 2 - 1).astype(np.float32)
-    of, ou = engine.empty(xin.shape), engine.empty((2, 16, 16, 3), np.uint8)
-    engine._check(engine.lib.dpir_finalize(engine.h, engine.to_device(xin).ptr, of.ptr, ou.ptr, 2, 16, 16))
+    of, ou, xd = engine.empty(xin.shape), engine.empty((2, 16, 16, 3), np.uint8), engine.to_device(xin)
+    engine._check(engine.lib.dpir_finalize(engine.h, xd.ptr, of.ptr, ou.ptr, 2, 16, 16))
     f = of.numpy()
     np.testing.assert_array_equal(f, (torch.from_numpy(xin) / 2 + 0.5).numpy())
     np.testing.assert_array_equal(ou.numpy(), do.tensor2uint_batch(torch.from_numpy(f)))

@@ -103,3 +103,18 @@ def test_factory_mirrors_reference_call_sequence():
     assert model.desc.model_channels == 128 and model.desc.out_channels == 6
     assert list(model.desc.attention_ds)[:1] == [16] and model.desc.n_channel_mult == 0
     assert diffusion.sqrt_recip_alphas_cumprod.dtype == np.float64
+
+
+def test_product_weight_schema_equals_oracle_and_reference():
+    """diffpir_amd.weights (product) and oracle.unet_oracle (checker) derive the reference's state-dict schema
+    independently; both must agree with each other (keys, shapes, order, values)."""
+    from diffpir_amd import weights
+    from oracle import unet_oracle as uo
+    for name, ohp in (("ffhq", uo.ffhq_hp()), ("tiny", uo.tiny_hp()), ("imagenet512", uo.imagenet512_hp())):
+        spec = weights.state_dict_spec(weights.model_hp(name))
+        ospec = uo.state_dict_spec(ohp)
+        assert [(k, tuple(s)) for k, s, _ in spec] == [(k, tuple(s)) for k, s, _ in ospec]
+    a = weights.synth_state_dict("tiny", 0)
+    b = uo.synth_state_dict(uo.tiny_hp(), 0)
+    for k in a:
+        np.testing.assert_array_equal(a[k], b[k].numpy())
