@@ -64,11 +64,6 @@ Status dpir_engine::resizer(int in_len, int sf, ResizerTab* out) {
     return Status{};
 }
 
-__global__ void fill_int_kernel(int* p, int v, int n) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = v;
-}
-
 extern "C" {
 
 int dpir_version(void) { return DPIR_ABI_VERSION; }
@@ -300,8 +295,8 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
 
 // out = blend ? base + g*((ifft)*oa+ob - base) : (ifft)*oa+ob ; input pre-map v = (x*pa+pb)*alpha
 static Status data_solution_impl(dpir_engine* e, const ProxState& st, const float* x, float pa, float pb, float alpha, float* out,
-                                 float oa, float ob, const float* blend_base, float g) {
-    if (!(alpha > 0.f)) return invalid("data_solution: alpha must be > 0");
+                                 float oa, float ob, const float* blend_base, float g, const StepDev* sp = nullptr) {
+    if (!sp && !(alpha > 0.f)) return invalid("data_solution: alpha must be > 0");
     FftPlan ph, pw;
     DPIR_TRY(e->fft_plan(st.H, &ph));
     DPIR_TRY(e->fft_plan(st.W, &pw));
@@ -309,8 +304,8 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
     DPIR_TRY(e->ws.getT("prox#buf", (size_t)st.B * 3 * st.H * st.W, &buf));
     hipStream_t s = e->stream;
     ProfScope ps(&e->prof, PC_FFT);
-    DPIR_TRY(launch_fft_rows_real3(s, pw, buf, x, pa, pb, alpha, st.B * 3, st.H, st.W));
-    SolveArgs a{st.FB, st.F2B, st.FBFy, alpha, st.sf};
+    DPIR_TRY(launch_fft_rows_real3(s, pw, buf, x, pa, pb, alpha, st.B * 3, st.H, st.W, sp));
+    SolveArgs a{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp};
     DPIR_TRY(launch_fft_cols_solve(s, ph, buf, a, st.B, st.H, st.W));
     float scale = 1.0f / ((float)st.H * (float)st.W);
     DPIR_TRY(launch_ifft_rows_real(s, pw, buf, out, scale, oa, ob, blend_base, g, st.B * 3, st.H, st.W));
@@ -357,13 +352,14 @@ int dpir_resize_down(dpir_engine* e, const float* x, float* out, int sf, int B, 
     return DPIR_OK;
 }
 
-static Status prox_ibp_impl(dpir_engine* e, float* x0, const float* y, float rho, float gamma, int in_iter, int sf, int B, int H, int W) {
+static Status prox_ibp_impl(dpir_engine* e, float* x0, const float* y, float rho, float gamma, int in_iter, int sf, int B, int H, int W,
+                            const StepDev* sp = nullptr) {
     float* d = nullptr;
     DPIR_TRY(e->ws.getT("ibp#down", (size_t)B * 3 * (H / sf) * (W / sf), &d));
     for (int it = 0; it < in_iter; ++it) {
         DPIR_TRY(resize_down_impl(e, x0, 0.5f, 0.5f, d, sf, B, H, W));      // down(x0/2+.5)
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_ibp_update(e->stream, x0, y, d, gamma, rho, sf, B * 3, H, W));
+        DPIR_TRY(launch_ibp_update(e->stream, x0, y, d, gamma, rho, sf, B * 3, H, W, sp));
     }
     return Status{};
 }
@@ -408,59 +404,66 @@ int dpir_randn(dpir_engine* e, float* out, uint64_t seed, uint64_t stream_id, in
 
 // ------------------------------------------------------------------------------------------ whole loop
 namespace {
-struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; };
+struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; StepDev *steps_dev, *cur; };
 
-Status loop_body(dpir_engine* e, const dpir_loop_desc& d, const dpir_step* steps, int n_steps, const LoopBufs& b,
-                 ProxState* prox, int first, int last_excl, bool do_init, bool do_finalize, float* out_f32, uint8_t* out_u8) {
+__global__ void fill_t_kernel(int* p, const StepDev* sp, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = sp->t;
+}
+
+// init (main_ddpir.py:291-320): x_T from y, spectra of the batch
+Status loop_init(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, ProxState* prox) {
     hipStream_t s = e->stream;
     const int B = d.B, H = d.H, W = d.W;
     const size_t total = (size_t)B * 3 * H * W;
-    if (do_init) {
-        const float* src = d.y_dev;
-        if (d.task == DPIR_TASK_SR_BLUR || d.task == DPIR_TASK_SR_CUBIC) {
-            ProfScope ps(&e->prof, PC_ELEM);
-            DPIR_TRY(launch_bicubic_up(s, d.y_dev, b.init_src, B * 3, H / d.sf, W / d.sf, d.sf));   // main_ddpir.py:295
-            src = b.init_src;
-        }
-        const float* n0 = d.noise_init_dev;
-        if (!n0) { DPIR_TRY(launch_randn(s, b.n2, d.seed, 0, d.image_offset, B, (size_t)3 * H * W)); n0 = b.n2; }
+    const float* src = d.y_dev;
+    if (d.task == DPIR_TASK_SR_BLUR || d.task == DPIR_TASK_SR_CUBIC) {
+        ProfScope ps(&e->prof, PC_ELEM);
+        DPIR_TRY(launch_bicubic_up(s, d.y_dev, b.init_src, B * 3, H / d.sf, W / d.sf, d.sf));   // main_ddpir.py:295
+        src = b.init_src;
+    }
+    const float* n0 = d.noise_init_dev;
+    if (!n0) { DPIR_TRY(launch_randn(s, b.n2, d.seed, 0, d.image_offset, B, (size_t)3 * H * W)); n0 = b.n2; }
+    {
         ProfScope ps(&e->prof, PC_ELEM);
         DPIR_TRY(launch_init_x(s, src, d.task == DPIR_TASK_INPAINT ? d.mask_dev : nullptr, n0, d.sa_start, d.s1m_start, b.x, total));
-        if (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR)
-            DPIR_TRY(prox_precalc(e, d.y_dev, d.k_dev, d.kh, d.kw, d.sf, B, H, W, prox));
     }
-    for (int i = first; i < last_excl; ++i) {
-        const dpir_step& st = steps[i];
-        if (st.last && d.skip_dead_final_eval) continue;
-        hipLaunchKernelGGL(fill_int_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, (int)st.t, B);
-        DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
-        {
-            ProfScope ps(&e->prof, PC_ELEM);
-            DPIR_TRY(launch_xstart(s, b.x, b.out6, e->net.desc.out_channels, st.c1, st.c2, b.x0, B, H * W));
-        }
-        if (st.last) continue;
-        if (d.task == DPIR_TASK_INPAINT) {
-            ProfScope ps(&e->prof, PC_ELEM);
-            DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, st.tau, d.guidance, total));
-        } else if (d.task == DPIR_TASK_SR_CUBIC) {
-            DPIR_TRY(prox_ibp_impl(e, b.x0, d.y_dev, st.tau, d.gamma, d.in_iter, d.sf, B, H, W));
-        } else {
-            DPIR_TRY(data_solution_impl(e, *prox, b.x0, 0.5f, 0.5f, st.tau, b.x0, 2.f, -1.f, b.x0, d.guidance));
-        }
-        const float *n1 = nullptr, *n2 = nullptr;
+    if (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR)
+        DPIR_TRY(prox_precalc(e, d.y_dev, d.k_dev, d.kh, d.kw, d.sf, B, H, W, prox));
+    return Status{};
+}
+
+// one iteration of main_ddpir.py:341-470; every per-step scalar is read on the device from b.cur
+Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, ProxState* prox, bool last, bool with_n1) {
+    hipStream_t s = e->stream;
+    const int B = d.B, H = d.H, W = d.W;
+    const size_t total = (size_t)B * 3 * H * W;
+    hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
+    DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
+    {
         ProfScope ps(&e->prof, PC_ELEM);
-        if (st.es != 0.f) {
-            if (d.noise_n1_dev) n1 = d.noise_n1_dev + (size_t)i * total;
-            else { DPIR_TRY(launch_randn(s, b.n1, d.seed, 1 + 2 * (uint64_t)i, d.image_offset, B, (size_t)3 * H * W)); n1 = b.n1; }
-        }
-        if (d.noise_n2_dev) n2 = d.noise_n2_dev + (size_t)i * total;
-        else { DPIR_TRY(launch_randn(s, b.n2, d.seed, 2 + 2 * (uint64_t)i, d.image_offset, B, (size_t)3 * H * W)); n2 = b.n2; }
-        DPIR_TRY(launch_renoise(s, b.x, b.x0, coef_of(st), n1, n2, total));
+        DPIR_TRY(launch_xstart(s, b.x, b.out6, e->net.desc.out_channels, 0.f, 0.f, b.x0, B, H * W, b.cur));
     }
-    if (do_finalize) {
+    if (last) return Status{};
+    if (d.task == DPIR_TASK_INPAINT) {
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_finalize(s, b.x, out_f32, out_u8, B, H * W));
+        DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, 0.f, d.guidance, total, b.cur));
+    } else if (d.task == DPIR_TASK_SR_CUBIC) {
+        DPIR_TRY(prox_ibp_impl(e, b.x0, d.y_dev, 0.f, d.gamma, d.in_iter, d.sf, B, H, W, b.cur));
+    } else {
+        DPIR_TRY(data_solution_impl(e, *prox, b.x0, 0.5f, 0.5f, 1.f, b.x0, 2.f, -1.f, b.x0, d.guidance, b.cur));
     }
+    const float *n1 = nullptr, *n2 = nullptr;
+    size_t stride = 0;
+    ProfScope ps(&e->prof, PC_ELEM);
+    if (with_n1) {
+        if (d.noise_n1_dev) n1 = d.noise_n1_dev;
+        else { DPIR_TRY(launch_randn(s, b.n1, d.seed, 1, d.image_offset, B, (size_t)3 * H * W, b.cur)); n1 = b.n1; }
+    }
+    if (d.noise_n2_dev) { n2 = d.noise_n2_dev; stride = total; }
+    else { DPIR_TRY(launch_randn(s, b.n2, d.seed, 2, d.image_offset, B, (size_t)3 * H * W, b.cur)); n2 = b.n2; }
+    if (with_n1 && d.noise_n1_dev && !d.noise_n2_dev) return invalid("host n1 noise requires host n2 noise");
+    DPIR_TRY(launch_renoise(s, b.x, b.x0, RenoiseCoef{}, n1, n2, total, b.cur, stride));
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -469,6 +472,27 @@ uint64_t fnv(uint64_t h, const void* p, size_t n) {
     const unsigned char* c = reinterpret_cast<const unsigned char*>(p);
     for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
     return h;
+}
+
+Status capture_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, ProxState* prox, bool last, bool with_n1,
+                    hipGraphExec_t* out) {
+    bool prof_on = e->prof.on, taps_on = e->collect_taps;
+    e->prof.on = false; e->collect_taps = false; e->ws.frozen = true;
+    hipGraph_t graph = nullptr;
+    Status cs;
+    hipError_t herr = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+    if (herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(herr)};
+    else {
+        cs = loop_step(e, d, b, prox, last, with_n1);
+        herr = hipStreamEndCapture(e->stream, &graph);
+        if (cs.ok() && herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(herr)};
+    }
+    e->ws.frozen = false; e->prof.on = prof_on; e->collect_taps = taps_on;
+    if (!cs.ok()) { if (graph) (void)hipGraphDestroy(graph); return cs; }
+    herr = hipGraphInstantiate(out, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (herr != hipSuccess) return Status{DPIR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(herr)};
+    return Status{};
 }
 }  // namespace
 
@@ -495,59 +519,79 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     API_TRY(e, e->ws.getT("loop#n2", total, &b.n2));
     API_TRY(e, e->ws.getT("loop#init", total, &b.init_src));
     API_TRY(e, e->ws.getT("loop#t", (size_t)B, &b.t_dev));
+    API_TRY(e, e->ws.getT("loop#steps", (size_t)n_steps, &b.steps_dev));
+    API_TRY(e, e->ws.getT("loop#cur", (size_t)1, &b.cur));
     API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
     bool need_prox = d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR;
     ProxState& prox = e->loop_prox;
     if (need_prox && (prox.B != B || prox.H != H || prox.W != W || !prox.FB)) {
         API_HIP(e, hipStreamSynchronize(e->stream));
         prox_release(&prox);
+        e->invalidate_graphs();
         API_TRY(e, prox_alloc(d.sf, B, H, W, &prox));
     }
     prox.sf = d.sf;
 
-    if (!d.use_graph) {
-        API_TRY(e, loop_body(e, d, steps, n_steps, b, &prox, 0, n_steps, true, true, out_f32, out_u8));
-        return DPIR_OK;
-    }
-    // ---- hipGraph path: the whole batch (init -> n_steps -> finalize) is one graph, cached by content
-    uint64_t key = fnv(1469598103934665603ull, &d, sizeof(d));
-    key = fnv(key, steps, sizeof(dpir_step) * n_steps);
-    key = fnv(key, &out_f32, sizeof(out_f32));
-    key = fnv(key, &out_u8, sizeof(out_u8));
-    key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
-    auto it = e->graphs.find(key);
-    if (it == e->graphs.end()) {
-        // warm-up: run the first step eagerly so that every workspace buffer exists before capture
-        bool prof_on = e->prof.on;
-        e->prof.on = false;
-        bool taps_on = e->collect_taps;
-        e->collect_taps = false;
-        Status ws = loop_body(e, d, steps, n_steps, b, &prox, 0, 1, true, false, nullptr, nullptr);
-        if (ws.ok() && hipStreamSynchronize(e->stream) != hipSuccess) ws = Status{DPIR_ERR_HIP, "warm-up step failed"};
-        if (!ws.ok()) { e->prof.on = prof_on; e->collect_taps = taps_on; return fail(e, ws); }
-        e->ws.frozen = true;
-        hipGraph_t graph = nullptr;
-        hipError_t herr = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
-        Status cs;
-        if (herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(herr)};
-        else {
-            cs = loop_body(e, d, steps, n_steps, b, &prox, 0, n_steps, true, true, out_f32, out_u8);
-            herr = hipStreamEndCapture(e->stream, &graph);
-            if (cs.ok() && herr != hipSuccess) cs = Status{DPIR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(herr)};
+    // per-step scalar table -> device (one small H2D per batch)
+    bool with_n1 = false;
+    {
+        std::vector<StepDev> hs(n_steps);
+        for (int i = 0; i < n_steps; ++i) {
+            const dpir_step& st = steps[i];
+            hs[i] = StepDev{st.t, st.last, i, 0, st.c1, st.c2, st.tau, st.sa_t, st.s1m_t, st.sa_p, st.k1, st.q, st.es, st.k2};
+            if (!st.last && st.es != 0.f) with_n1 = true;
+            if (st.last && i != n_steps - 1) return fail(e, invalid("dpir_run_loop: only the final step may be marked last"));
         }
-        e->ws.frozen = false;
-        e->prof.on = prof_on;
-        e->collect_taps = taps_on;
-        if (!cs.ok()) { if (graph) (void)hipGraphDestroy(graph); return fail(e, cs); }
-        hipGraphExec_t exec = nullptr;
-        herr = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-        (void)hipGraphDestroy(graph);
-        if (herr != hipSuccess) return fail(e, Status{DPIR_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(herr)});
-        dpir_engine::GraphEntry ge; ge.exec = exec;
-        it = e->graphs.insert({key, ge}).first;
+        API_HIP(e, hipMemcpyAsync(b.steps_dev, hs.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, e->stream));
+        API_HIP(e, hipStreamSynchronize(e->stream));
     }
-    ProfScope ps(&e->prof, PC_LOOP);
-    API_HIP(e, hipGraphLaunch(it->second.exec, e->stream));
+    if (with_n1 && d.noise_n2_dev && !d.noise_n1_dev) return fail(e, invalid("dpir_run_loop: eta != 0 with host noise needs noise_n1_dev"));
+
+    API_TRY(e, loop_init(e, d, b, &prox));
+    hipGraphExec_t g_step = nullptr, g_last = nullptr;
+    for (int i = 0; i < n_steps; ++i) {
+        const bool last = steps[i].last != 0;
+        if (last && d.skip_dead_final_eval) continue;
+        API_HIP(e, hipMemcpyAsync(b.cur, b.steps_dev + i, sizeof(StepDev), hipMemcpyDeviceToDevice, e->stream));
+        if (!d.use_graph) {
+            API_TRY(e, loop_step(e, d, b, &prox, last, with_n1));
+            continue;
+        }
+        hipGraphExec_t& g = last ? g_last : g_step;
+        if (!g) {
+            // one graph per (descriptor, workspace generation, step kind); the descriptor holds every pointer baked in
+            uint64_t key = fnv(1469598103934665603ull, &d, sizeof(d));
+            key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
+            int kind = (last ? 1 : 0) | (with_n1 ? 2 : 0);
+            key = fnv(key, &kind, sizeof(kind));
+            auto it = e->graphs.find(key);
+            if (it == e->graphs.end()) {
+                // warm-up: run this step eagerly once so that every workspace buffer exists before capture
+                // (it is a real step of the loop: its result is kept and the graph is used from the next one)
+                uint64_t gen0 = e->ws.generation;
+                API_TRY(e, loop_step(e, d, b, &prox, last, with_n1));
+                if (e->ws.generation != gen0) {   // buffers were created: keys must use the settled generation
+                    key = fnv(1469598103934665603ull, &d, sizeof(d));
+                    key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
+                    key = fnv(key, &kind, sizeof(kind));
+                }
+                API_HIP(e, hipStreamSynchronize(e->stream));
+                hipGraphExec_t exec = nullptr;
+                API_TRY(e, capture_step(e, d, b, &prox, last, with_n1, &exec));
+                dpir_engine::GraphEntry ge; ge.exec = exec;
+                e->graphs[key] = ge;
+                g = exec;
+                continue;   // this step was executed eagerly
+            }
+            g = it->second.exec;
+        }
+        ProfScope ps(&e->prof, PC_LOOP);
+        API_HIP(e, hipGraphLaunch(g, e->stream));
+    }
+    {
+        ProfScope ps(&e->prof, PC_ELEM);
+        API_TRY(e, launch_finalize(e->stream, b.x, out_f32, out_u8, B, H * W));
+    }
     return DPIR_OK;
 }
 

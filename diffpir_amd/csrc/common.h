@@ -104,6 +104,8 @@ struct ConvArgs {
     int res_mode = 0;             // 0 plain, 1 up, 2 down (same meaning as src.mode)
     int B = 0, Cin = 0, Cout = 0, CoutP = 0, H = 0, W = 0;
     int ks = 3;                   // 3 or 1
+    float* partial = nullptr;     // split-K slab (optional) and its capacity in floats
+    size_t partial_capacity = 0;
 };
 Status launch_conv(hipStream_t s, const ConvArgs& a);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -31,6 +31,10 @@ struct ConvK {
     int n_ptiles;          // total pixel tiles
     int n_co_blocks;
     int chs;               // LDS activation channel stride (floats)
+    int ksplit;            // >1: split the Cin chunks over ksplit workgroups, raw partial sums go to `partial`
+    int chunks_per_split;
+    float* partial;        // [ksplit][B*Cout*H*W]
+    size_t partial_cap;    // host-side: floats available in `partial`
 };
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
@@ -53,7 +57,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     const int wave_co = wave % WAVES_CO;
     const int wave_px = wave / WAVES_CO;
 
-    const int bid = blockIdx.x;
+    int bid = blockIdx.x;
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
     const int co_blk = bid % p.n_co_blocks;
     const int ptile = bid / p.n_co_blocks;
     const int co0 = co_blk * BCO;
@@ -117,43 +123,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if (p.prm && tid < KC * 8) {   // parameters of chunk 0 (visible after the loop-top barrier)
+    const int c_begin = split * p.chunks_per_split * KC;
+    const int c_end = min(p.Cin, c_begin + p.chunks_per_split * KC);
+    if (p.prm && tid < KC * 8) {   // parameters of the first chunk (visible after the loop-top barrier)
         int k = tid >> 3, ti = tid & 7;
-        int n = n0 + ti;
+        int c = c_begin + k, n = n0 + ti;
         float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (k < p.Cin && ti < TI && n < p.B) m = p.prm[(size_t)n * C + k];
+        if (c < p.Cin && ti < TI && n < p.B) m = p.prm[(size_t)n * C + c];
         lds_prm[k * 8 + ti] = m;
     }
-    for (int c0 = 0; c0 < p.Cin; c0 += KC) {
-        __syncthreads();
-        // ---- stage weights chunk: global [Cin][TAPS][CoutP] -> lds [TAPS][KC][BCO], float4 along co
-        {
-            constexpr int NV = TAPS * KC * BCO / 4;
-            for (int v = tid; v < NV; v += 256) {
-                int co4 = v % (BCO / 4);
-                int t2 = v / (BCO / 4);
-                int tap = t2 % TAPS;
-                int k = t2 / TAPS;
-                int c = c0 + k;
-                int co = co0 + co4 * 4;
-                float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (c < p.Cin && co < p.CoutP)
-                    val = *reinterpret_cast<const float4*>(p.w + ((size_t)c * TAPS + tap) * p.CoutP + co);
-                *reinterpret_cast<float4*>(lds_w + (tap * KC + k) * BCO + co4 * 4) = val;
-            }
+    // ---- software pipeline: the NEXT chunk's global loads are issued before the MFMA phase of the current
+    // chunk and land in registers while the matrix pipe is busy (weights: NWV float4, activations KC x NP)
+    constexpr int NV = TAPS * KC * BCO / 4;
+    constexpr int NWV = (NV + 255) / 256;
+    float4 wreg[NWV];
+    float vals[KC][NP];
+    auto load_chunk = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            int v = tid + u * 256;
+            int co4 = v % (BCO / 4);
+            int t2 = v / (BCO / 4);
+            int tap = t2 % TAPS;
+            int k = t2 / TAPS;
+            int c = c0 + k;
+            int co = co0 + co4 * 4;
+            float4 val = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (v < NV && c < p.Cin && co < p.CoutP)
+                val = *reinterpret_cast<const float4*>(p.w + ((size_t)c * TAPS + tap) * p.CoutP + co);
+            wreg[u] = val;
         }
-        // ---- prefetch the NEXT chunk's GroupNorm/FiLM parameters into the other LDS buffer
-        const int pbuf = (c0 / KC) & 1;
-        if (p.prm && tid < KC * 8) {
-            int k = tid >> 3, ti = tid & 7;
-            int c = c0 + KC + k, n = n0 + ti;
-            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (c < p.Cin && ti < TI && n < p.B) m = p.prm[(size_t)n * C + c];
-            lds_prm[((pbuf ^ 1) * KC + k) * 8 + ti] = m;
-        }
-        // ---- stage activation patch with the fused prologue
         if (MODE != 2) {
-            float vals[KC][NP];
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 int c = c0 + k;
@@ -166,6 +166,34 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
                     vals[k][q] = ok ? plane[((size_t)pos_n[q] * cs + cc) * HsWs + pos_src[q]] : 0.f;
                 }
             }
+        }
+    };
+    load_chunk(c_begin);
+    for (int c0 = c_begin; c0 < c_end; c0 += KC) {
+        __syncthreads();
+        // ---- registers -> LDS: weights [TAPS][KC][BCO]
+#pragma unroll
+        for (int u = 0; u < NWV; ++u) {
+            int v = tid + u * 256;
+            if (v < NV) {
+                int co4 = v % (BCO / 4);
+                int t2 = v / (BCO / 4);
+                int tap = t2 % TAPS;
+                int k = t2 / TAPS;
+                *reinterpret_cast<float4*>(lds_w + (tap * KC + k) * BCO + co4 * 4) = wreg[u];
+            }
+        }
+        // ---- prefetch the NEXT chunk's GroupNorm/FiLM parameters into the other LDS buffer
+        const int pbuf = ((c0 - c_begin) / KC) & 1;
+        if (p.prm && tid < KC * 8) {
+            int k = tid >> 3, ti = tid & 7;
+            int c = c0 + KC + k, n = n0 + ti;
+            float4 m = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (c < p.Cin && ti < TI && n < p.B) m = p.prm[(size_t)n * C + c];
+            lds_prm[((pbuf ^ 1) * KC + k) * 8 + ti] = m;
+        }
+        // ---- registers -> LDS: activation patch with the fused prologue
+        if (MODE != 2) {
 #pragma unroll
             for (int k = 0; k < KC; ++k) {
                 bool cok = (c0 + k) < p.Cin;
@@ -209,6 +237,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
             }
         }
         __syncthreads();
+        if (c0 + KC < c_end) load_chunk(c0 + KC);
         // ---- MFMA over taps x channel pairs
 #pragma unroll
         for (int tap = 0; tap < TAPS; ++tap) {
@@ -244,7 +273,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int co = co0 + (wave_co * WCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (pok && co < p.Cout) {
+                if (pok && co < p.Cout && p.ksplit > 1) {
+                    p.partial[(size_t)split * ((size_t)p.B * p.Cout * HW) + ((size_t)n * p.Cout + co) * HW + y * p.W + x] = acc[i][j][r];
+                } else if (pok && co < p.Cout) {
                     float v = acc[i][j][r] + p.bias[co];
                     if (p.res) {
                         float rv;
@@ -267,6 +298,29 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
     }
 }
 
+// deterministic split-K combine: out = sum_s partial[s] (in order) + bias + residual
+__global__ void conv_splitk_reduce_kernel(const float* partial, int ksplit, const float* bias, const float* res, int res_mode,
+                                          float* out, int Cout, int H, int W, size_t total) {
+    const int HW = H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += partial[(size_t)s * total + i];
+        size_t nc = i / HW;
+        int co = (int)(nc % Cout);
+        v += bias[co];
+        if (res) {
+            int r = (int)(i - nc * HW);
+            int y = r / W, x = r - y * W;
+            float rv;
+            if (res_mode == 0) rv = res[i];
+            else if (res_mode == 1) { int Hr = H >> 1, Wr = W >> 1; rv = res[nc * (size_t)(Hr * Wr) + (y >> 1) * Wr + (x >> 1)]; }
+            else { int Wr = W * 2; const float* rp = res + nc * (size_t)(4 * HW) + (2 * y) * Wr + 2 * x; rv = ((rp[0] + rp[1]) + (rp[Wr] + rp[Wr + 1])) * 0.25f; }
+            v = rv + v;
+        }
+        out[i] = v;
+    }
+}
+
 static int ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 template <int KS, int KC, int WAVES_CO, int WCO, int WPX, int MODE>
@@ -281,8 +335,30 @@ static Status launch_mode(hipStream_t s, ConvK k) {
         DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         attr_set = true;
     }
-    dim3 grid((unsigned)(k.n_ptiles * k.n_co_blocks));
+    // split-K for launches that cannot fill 256 CUs x 2 workgroups (low-resolution layers): partial slabs +
+    // an ordered reduce, so results stay bitwise reproducible
+    const int chunks = (k.Cin + KC - 1) / KC;
+    const int blocks = k.n_ptiles * k.n_co_blocks;
+    int S = 1;
+    if (k.partial && blocks < 384) {
+        S = (512 + blocks - 1) / blocks;
+        if (S > chunks / 4) S = chunks / 4;
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+        size_t need = (size_t)S * k.B * k.Cout * k.H * k.W;
+        if (need > k.partial_cap) S = 1;
+    }
+    k.ksplit = S;
+    k.chunks_per_split = (chunks + S - 1) / S;
+    if (S == 1) k.partial = nullptr;
+    dim3 grid((unsigned)(blocks * S));
     hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, k);
+    if (S > 1) {
+        size_t total = (size_t)k.B * k.Cout * k.H * k.W;
+        unsigned nb = (unsigned)((total + 255) / 256);
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, k.partial, S, k.bias, k.res, k.res_mode, k.out,
+                           k.Cout, k.H, k.W, total);
+    }
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -303,6 +379,8 @@ Status launch_conv(hipStream_t s, const ConvArgs& a) {
     k.mode = a.src.mode; k.prm = a.src.prm;
     k.w = a.w; k.bias = a.bias; k.out = a.out; k.res = a.res; k.res_mode = a.res_mode;
     k.B = a.B; k.Cin = a.Cin; k.Cout = a.Cout; k.CoutP = a.CoutP; k.H = a.H; k.W = a.W;
+    k.partial = a.partial; k.ksplit = 1; k.chunks_per_split = 0;
+    k.partial_cap = a.partial_capacity;
     // expected source resolution for the resampling mode
     int eh = a.src.mode == 1 ? a.H / 2 : (a.src.mode == 2 ? a.H * 2 : a.H);
     int ew = a.src.mode == 1 ? a.W / 2 : (a.src.mode == 2 ? a.W * 2 : a.W);

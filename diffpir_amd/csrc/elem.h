@@ -6,17 +6,28 @@ namespace dpir {
 
 struct RenoiseCoef { float sa_t, s1m_t, sa_p, k1, q, es, k2; };
 
-Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW);
-Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total);
-Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total);
+// Device-resident copy of the CURRENT step's scalars.  Inside dpir_run_loop every kernel that needs a per-step
+// scalar reads it from here (fixed address), so that one captured hipGraph serves all steps: the host only
+// copies steps_dev[i] -> cur (16 words, stream-ordered D2D) before each replay.
+struct StepDev {
+    int t, last, i, pad;
+    float c1, c2, tau, sa_t, s1m_t, sa_p, k1, q, es, k2;
+};
+
+Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW, const StepDev* sp = nullptr);
+Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp = nullptr);
+Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total,
+                      const StepDev* sp = nullptr, size_t noise_step_stride = 0);
 Status launch_init_x(hipStream_t s, const float* src, const uint8_t* mask, const float* noise, float sa, float s1m, float* x, size_t total);
 Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW);
 Status launch_affine(hipStream_t s, const float* x, float a, float b, float* out, size_t total);
 Status launch_band_resample(hipStream_t s, const float* in, const float* w, const int* idx, int taps, int P, int L_in,
                             int L_out, int inner, float pa, float pb, float* out);
-Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W);
+Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W,
+                         const StepDev* sp = nullptr);
 Status launch_bicubic_up(hipStream_t s, const float* in, float* out, int P, int h, int w, int sf);
-Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image);
+Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image,
+                    const StepDev* sp = nullptr);   // sp: stream_id += 2 * sp->i
 void resizer_band(int in_len, int out_len, double scale, std::vector<float>& w_out, std::vector<int>& idx_out, int& taps_out);
 
 // fft.hip ------------------------------------------------------------------------------------
@@ -30,7 +41,7 @@ struct FftPlan {
 Status launch_fft_rows(hipStream_t s, const FftPlan& pw, float2* buf, const float* real_in, float pa, float pb,
                        int P, int H, int W, bool inverse);
 Status launch_fft_rows_real3(hipStream_t s, const FftPlan& pw, float2* buf, const float* real_in, float pa, float pb, float pm,
-                             int P, int H, int W);
+                             int P, int H, int W, const StepDev* sp = nullptr);   // sp: pm = sp->tau
 // columns forward only (used by pre_calculate)
 Status launch_fft_cols(hipStream_t s, const FftPlan& ph, float2* buf, int P, int H, int W, bool inverse);
 // fused column pass of data_solution: col-FFT -> closed-form spectral solve -> inverse col-FFT
@@ -40,6 +51,7 @@ struct SolveArgs {
     const float* F2B;    // [B,1,H,W]
     const float2* FBFy;  // [B,3,H,W]
     float alpha; int sf;
+    const StepDev* sp;   // non-null: alpha = sp->tau
 };
 Status launch_fft_cols_solve(hipStream_t s, const FftPlan& ph, float2* buf, const SolveArgs& a, int B, int H, int W);
 // inverse rows with real output: out = Re(ifft_row)*oa + ob, optionally blended: out = base + g*(val - base)

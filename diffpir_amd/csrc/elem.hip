@@ -19,7 +19,9 @@ static inline dim3 grid1d(size_t n, int per_block = 256) {
 #define GRID_STRIDE(i, n) for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < (n); i += (size_t)gridDim.x * blockDim.x)
 
 // ---------------------------------------------------------------- eps -> clamped x0
-__global__ void xstart_kernel(const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, size_t chw, size_t total) {
+__global__ void xstart_kernel(const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, size_t chw, size_t total,
+                              const StepDev* sp) {
+    if (sp) { c1 = sp->c1; c2 = sp->c2; }
     GRID_STRIDE(i, total) {
         size_t n = i / chw, r = i - n * chw;
         float eps = out6[n * (chw / 3) * out_ch + r];
@@ -27,15 +29,16 @@ __global__ void xstart_kernel(const float* x, const float* out6, int out_ch, flo
         x0[i] = fminf(fmaxf(v, -1.0f), 1.0f);
     }
 }
-Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW) {
+Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW, const StepDev* sp) {
     size_t total = (size_t)B * 3 * HW;
-    hipLaunchKernelGGL(xstart_kernel, grid1d(total), dim3(256), 0, s, x, out6, out_ch, c1, c2, x0, (size_t)3 * HW, total);
+    hipLaunchKernelGGL(xstart_kernel, grid1d(total), dim3(256), 0, s, x, out6, out_ch, c1, c2, x0, (size_t)3 * HW, total, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
 // ---------------------------------------------------------------- masked prox
-__global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total) {
+__global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp) {
+    if (sp) tau = sp->tau;
     GRID_STRIDE(i, total) {
         float m = (float)mask[i];
         float v = x0[i];
@@ -44,14 +47,20 @@ __global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask,
         x0[i] = v + g * (xp - v);
     }
 }
-Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total) {
-    hipLaunchKernelGGL(prox_mask_kernel, grid1d(total), dim3(256), 0, s, x0, y, mask, tau, g, total);
+Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp) {
+    hipLaunchKernelGGL(prox_mask_kernel, grid1d(total), dim3(256), 0, s, x0, y, mask, tau, g, total, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
 // ---------------------------------------------------------------- re-noise
-__global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const float* n1, const float* n2, size_t total) {
+__global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const float* n1, const float* n2, size_t total,
+                               const StepDev* sp, size_t stride) {
+    if (sp) {
+        c.sa_t = sp->sa_t; c.s1m_t = sp->s1m_t; c.sa_p = sp->sa_p; c.k1 = sp->k1; c.q = sp->q; c.es = sp->es; c.k2 = sp->k2;
+        if (n1) n1 += (size_t)sp->i * stride;
+        n2 += (size_t)sp->i * stride;
+    }
     GRID_STRIDE(i, total) {
         float a = x0[i];
         float eps = (x[i] - c.sa_t * a) / c.s1m_t;
@@ -62,8 +71,9 @@ __global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const f
         x[i] = v;
     }
 }
-Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total) {
-    hipLaunchKernelGGL(renoise_kernel, grid1d(total), dim3(256), 0, s, x, x0, c, n1, n2, total);
+Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total,
+                      const StepDev* sp, size_t noise_step_stride) {
+    hipLaunchKernelGGL(renoise_kernel, grid1d(total), dim3(256), 0, s, x, x0, c, n1, n2, total, sp, noise_step_stride);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -140,7 +150,9 @@ Status launch_band_resample(hipStream_t s, const float* in, const float* w, cons
 }
 
 // IBP update: x0 <- 2*( z + gamma*(y - d)[up nearest]/(1+rho) ) - 1, z = x0/2+.5   (main_ddpir.py:404-406)
-__global__ void ibp_update_kernel(float* x0, const float* y, const float* d, float gamma, float rho, int sf, int H, int W, size_t total) {
+__global__ void ibp_update_kernel(float* x0, const float* y, const float* d, float gamma, float rho, int sf, int H, int W, size_t total,
+                                  const StepDev* sp) {
+    if (sp) rho = sp->tau;
     GRID_STRIDE(i, total) {
         size_t plane = i / ((size_t)H * W);
         size_t r = i - plane * (size_t)H * W;
@@ -153,9 +165,10 @@ __global__ void ibp_update_kernel(float* x0, const float* y, const float* d, flo
         x0[i] = z * 2.0f - 1.0f;
     }
 }
-Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W) {
+Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W,
+                         const StepDev* sp) {
     size_t total = (size_t)P * H * W;
-    hipLaunchKernelGGL(ibp_update_kernel, grid1d(total), dim3(256), 0, s, x0, y, d, gamma, rho, sf, H, W, total);
+    hipLaunchKernelGGL(ibp_update_kernel, grid1d(total), dim3(256), 0, s, x0, y, d, gamma, rho, sf, H, W, total, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -216,7 +229,9 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
 __device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
 
 // one thread produces 4 normals for elements [4j, 4j+4) of image (image_offset + n); counter = (j, image, stream)
-__global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, size_t per_image, size_t total4) {
+__global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, size_t per_image, size_t total4,
+                             const StepDev* sp) {
+    if (sp) stream_id += 2 * (uint64_t)sp->i;
     GRID_STRIDE(i, total4) {
         size_t q = (per_image + 3) / 4;
         size_t n = i / q, j = i - n * q;
@@ -238,9 +253,10 @@ __global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int6
             if (j * 4 + e < per_image) o[e] = z[e];
     }
 }
-Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image) {
+Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image,
+                    const StepDev* sp) {
     size_t total4 = (size_t)B * ((per_image + 3) / 4);
-    hipLaunchKernelGGL(randn_kernel, grid1d(total4), dim3(256), 0, s, out, seed, stream_id, image_offset, per_image, total4);
+    hipLaunchKernelGGL(randn_kernel, grid1d(total4), dim3(256), 0, s, out, seed, stream_id, image_offset, per_image, total4, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

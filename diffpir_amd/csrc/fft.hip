@@ -57,10 +57,11 @@ __device__ __forceinline__ void load_twiddles(float2* lds_tw, const float2* tw, 
 // ---------------------------------------------------------------- rows, forward (optionally real input)
 // grid: total_rows / R blocks; block: 256 threads; R rows of W points
 __global__ __launch_bounds__(256) void fft_rows_fwd_kernel(float2* buf, const float* real_in, float pa, float pb, float pm,
-                                                            int W, int logW, int R, size_t total_rows, const float2* tw) {
+                                                            int W, int logW, int R, size_t total_rows, const float2* tw, const StepDev* sp) {
     extern __shared__ __attribute__((aligned(16))) float2 sm[];
     float2* lds_tw = sm;
     float2* d = sm + (W >> 1);
+    if (sp) pm = sp->tau;
     load_twiddles(lds_tw, tw, W);
     size_t row0 = (size_t)blockIdx.x * R;
     for (int i = threadIdx.x; i < R * W; i += 256) {
@@ -128,6 +129,7 @@ __global__ __launch_bounds__(256) void fft_cols_kernel(float2* buf, SolveArgs a,
     __syncthreads();
     if (MODE != 1) batched_fft_lds<false>(d, CW, HS, logH, lds_tw);
     if (MODE == 2) {
+        if (a.sp) a.alpha = a.sp->tau;
         // one work item per sf x sf alias tile (rows/cols are in bit-reversed storage order)
         const int sf = a.sf;
         const int n_img = plane / 3;
@@ -191,21 +193,21 @@ Status launch_fft_rows(hipStream_t s, const FftPlan& pw, float2* buf, const floa
     size_t rows = (size_t)P * H;
     size_t lds = ((W >> 1) + (size_t)R * W) * sizeof(float2);
     hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3((unsigned)((rows + R - 1) / R)), dim3(256), lds, s, buf, real_in, pa, pb, 1.0f,
-                       W, pw.logN, R, rows, pw.tw);
+                       W, pw.logN, R, rows, pw.tw, (const StepDev*)nullptr);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
 // real input with the reference's two-step prologue: v = (x*pa + pb) * pm
 Status launch_fft_rows_real3(hipStream_t s, const FftPlan& pw, float2* buf, const float* real_in, float pa, float pb, float pm,
-                             int P, int H, int W) {
+                             int P, int H, int W, const StepDev* sp) {
     DPIR_TRY(check_dims(H, W));
     if (pw.N != W) return invalid("fft rows: plan size mismatch");
     int R = W >= 1024 ? 1 : 1024 / W;
     size_t rows = (size_t)P * H;
     size_t lds = ((W >> 1) + (size_t)R * W) * sizeof(float2);
     hipLaunchKernelGGL(fft_rows_fwd_kernel, dim3((unsigned)((rows + R - 1) / R)), dim3(256), lds, s, buf, real_in, pa, pb, pm,
-                       W, pw.logN, R, rows, pw.tw);
+                       W, pw.logN, R, rows, pw.tw, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -228,6 +230,7 @@ static Status launch_cols_mode(hipStream_t s, const FftPlan& ph, float2* buf, co
 
 Status launch_fft_cols(hipStream_t s, const FftPlan& ph, float2* buf, int P, int H, int W, bool inverse) {
     SolveArgs a{};
+    a.sp = nullptr;
     return inverse ? launch_cols_mode<1>(s, ph, buf, a, P, H, W) : launch_cols_mode<0>(s, ph, buf, a, P, H, W);
 }
 

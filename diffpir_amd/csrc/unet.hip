@@ -258,6 +258,8 @@ struct Fwd {
     int B;
     const float* film;     // [B, film_rows]
     int film_rows;
+    float* partial;        // split-K slab shared by all convolutions of the forward
+    size_t partial_cap;
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
         ConvArgs a;
@@ -265,6 +267,7 @@ struct Fwd {
         a.src.mode = mode; a.src.prm = prm;
         a.w = cw.w; a.bias = cw.bias; a.out = out; a.res = res; a.res_mode = res_mode;
         a.B = B; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutP = cw.coutp; a.H = Ho; a.W = Wo; a.ks = cw.ks;
+        a.partial = partial; a.partial_capacity = partial_cap;
         ProfScope ps(&e->prof, cw.ks == 3 ? PC_CONV3 : PC_CONV1);
         return launch_conv(s, a);
     }
@@ -374,7 +377,11 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         DPIR_TRY(launch_time_embed(s, t_dev, y_dev, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, net.label_emb, B, mc, tmp, semb));
         DPIR_TRY(launch_rows_gemv(s, net.film_w, net.film_b, semb, B, net.film_rows, ted, film));
     }
-    Fwd f{e, s, ws, B, film, net.film_rows};
+    // split-K slab: 16 slices of the largest low-resolution output (layers with < 384 workgroups)
+    float* partial = nullptr;
+    size_t partial_cap = (size_t)16 * 1024 * 1024;   // 64 MiB
+    DPIR_TRY(ws.getT("conv#partial", partial_cap, &partial));
+    Fwd f{e, s, ws, B, film, net.film_rows, partial, partial_cap};
     if (e->collect_taps) e->taps.clear();
 
     std::vector<Act> hs;

@@ -30,7 +30,7 @@ def main():
     # timing of the FFHQ forward at 256x256
     hp = uo.ffhq_hp()
     model, sd = make_model(e, hp)
-    for B in (1, 4):
+    for B in (1, 4, 16):
         x = e.to_device(np.random.default_rng(0).standard_normal((B, 3, 256, 256)).astype(np.float32))
         t = np.full(B, 500)
         out = e.unet_forward(x, t); e.sync()
