@@ -46,7 +46,8 @@ def parse():
     ap.add_argument("--model", default="ffhq", choices=["ffhq", "imagenet256"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-nfe", type=int, default=8, help="NFE steps of the CPU oracle sample (B=1)")
+    ap.add_argument("--cpu-nfe", type=int, default=6, help="NFE steps of the CPU oracle sample (B=1)")
+    ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle sample (all 256 host\n                    threads oversubscribe MKL-DNN at B=1: 79 s/NFE measured vs ~1-2 s/NFE at 32)")
     return ap.parse_args()
 
 
@@ -166,13 +167,14 @@ def main():
         yy = th.from_numpy(case["y"][:1])
         kk_ = None if case["k"] is None else th.from_numpy(case["k"][:1])
         mm = None if case["mask"] is None else th.from_numpy(case["mask"][:1]).float()
-        th.set_num_threads(os.cpu_count())
+        th.set_num_threads(max(1, min(args.cpu_threads, os.cpu_count())))
         tc = time.perf_counter()
         do.restore(sd, ohp, ocfg, yy, k=kk_, mask=mm, noise_fn=nf)
         tcpu = time.perf_counter() - tc
         per_nfe = tcpu / nfe
         cpu = {"value": round(1.0 / (per_nfe * args.nfe), 6), "unit": "images/s", "cores": th.get_num_threads(),
-               "kind": "port", "sample": f"oracle (torch-CPU fp32 restatement of the reference loop), B=1, {nfe} NFE "
+               "host_cores": os.cpu_count(), "kind": "port",
+               "sample": f"oracle (torch-CPU fp32 restatement of the reference loop), B=1, {nfe} NFE "
                f"at {H}x{H} in {tcpu:.1f} s, extrapolated linearly to {args.nfe} NFE"}
 
     if rank == 0:
