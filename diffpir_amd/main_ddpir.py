@@ -1,0 +1,184 @@
+"""YAML-driven batched driver with the reference's config surface (main_ddpir.py:127-169, 172-599), on the engine.
+
+    python -m diffpir_amd.main_ddpir --opt <config.yaml> [--synthetic N] [--device 0]
+
+Accepts the reference's configs/*.yaml unchanged.  What it keeps from the reference driver: the derived fields
+(noise_level_img/255, sigma = max(0.001, .), kernel_std), the per-task lambda/zeta sweeps (main_ddpir.py:548-580),
+the per-image degradation recipe (main_ddpir.py:46-117) and the batch PSNR log line.  What it does differently:
+the loop body is one engine call (restore.restore_batch), images are read / written with PIL when available (cv2
+is not installed here), LPIPS is skipped (package absent; `calc_LPIPS` is honoured as "not available"), and with no
+dataset / checkpoint on disk it falls back to synthetic ground truth and synthetic weights, saying so in the log.
+"""
+from __future__ import annotations
+
+import argparse
+import glob
+import logging
+import os
+import time
+
+import numpy as np
+import yaml
+
+from . import restore, synth, script_util, utils_model, weights
+from .engine import Engine
+from .utils_inpaint import mask_generator
+
+log = logging.getLogger("diffpir_amd")
+
+
+class Config:
+    def __init__(self, dictionary):
+        for k, v in dictionary.items():
+            setattr(self, k, Config(v) if isinstance(v, dict) else v)
+
+    def get(self, k, default=None):
+        return getattr(self, k, default)
+
+
+def parse_config(path):
+    with open(path, "r") as f:
+        config = Config(yaml.safe_load(f))
+    config.opt = path
+    config.noise_level_img = config.noise_level_img / 255.0              # main_ddpir.py:138
+    config.noise_level_model = config.noise_level_img                    # :140
+    config.sigma = max(0.001, config.noise_level_img)                    # :141
+    if config.task == "deblur":
+        config.kernel_std = 3.0 if config.blur_mode == "Gaussian" else 0.5   # :151
+    if config.task == "inpaint":
+        assert config.generate_mode in ["DiffPIR", "repaint", "vanilla"]
+    for k, d in dict(sr_mode="blur", inIter=1, gamma=0.01, sf=1).items():
+        if not hasattr(config, k):
+            setattr(config, k, d)
+    return config
+
+
+def loop_config(config, lambda_, zeta) -> restore.LoopConfig:
+    return restore.LoopConfig(task=config.task, iter_num=config.iter_num, noise_level_img=config.noise_level_img,
+                              lambda_=lambda_, zeta=zeta, eta=config.eta, guidance_scale=config.guidance_scale,
+                              sf=config.sf, sr_mode=config.sr_mode, inIter=config.inIter, gamma=config.gamma,
+                              skip_type=config.skip_type, num_train_timesteps=config.num_train_timesteps,
+                              beta_start=config.beta_start, beta_end=config.beta_end, generate_mode=config.generate_mode,
+                              model_output_type=config.model_output_type, sub_1_analytic=config.sub_1_analytic,
+                              ddim_sample=config.ddim_sample, iter_num_U=config.iter_num_U)
+
+
+def sweeps(config):
+    """main_ddpir.py:548-580."""
+    if config.task == "sr":
+        return [(config.lambda_ * i, config.zeta) for i in range(2, 13)]
+    if config.task == "deblur":
+        return [(config.lambda_ * 7, config.zeta * 3)]
+    return [(config.lambda_ * 1, config.zeta * 1)]
+
+
+def load_images(config, n_synth):
+    """[N,3,H,W] float32 in [0,1] + names.  testsets/<testset_name>/*.png via PIL when present, else synthetic."""
+    d = os.path.join(config.get("cwd", "") or "", "testsets", config.testset_name)
+    paths = sorted(glob.glob(os.path.join(d, "*.png")) + glob.glob(os.path.join(d, "*.jpg")))
+    if paths and not n_synth:
+        try:
+            from PIL import Image
+            imgs = [np.asarray(Image.open(p).convert("RGB"), np.float32).transpose(2, 0, 1) / 255.0 for p in paths]
+            return np.stack(imgs), [os.path.basename(p) for p in paths]
+        except Exception as ex:   # pragma: no cover
+            log.warning("cannot read %s (%s); using synthetic images", d, ex)
+    n = n_synth or 16
+    log.info("no dataset on disk: using %d synthetic 256x256 ground-truth images", n)
+    return synth.smooth_images(n, 256, 256, 42), [f"synth_{i:04d}.png" for i in range(n)]
+
+
+def degrade(config, gt, idx0):
+    """CustomDataset.__getitem__ (main_ddpir.py:46-117) for a batch; returns y, k, mask (numpy, loop layouts)."""
+    from scipy import ndimage
+    B, _, H, W = gt.shape
+    k = mask = None
+    if config.task == "deblur":
+        ks = []
+        y = np.empty_like(gt)
+        for b in range(B):
+            np.random.seed(seed=(idx0 + b) * 10)
+            if config.blur_mode == "Gaussian":
+                kern = synth.gaussian_psf(config.kernel_size, config.kernel_std * np.abs(np.random.rand() * 2 + 1))
+            else:
+                kern = synth.motion_psf(config.kernel_size, seed=idx0 + b)
+            ks.append(kern)
+            for c in range(3):
+                y[b, c] = ndimage.convolve(gt[b, c], kern, mode="wrap")
+        k = np.stack(ks)[:, None].astype(np.float32)
+    elif config.task == "sr":
+        y = synth.resize_down(gt, config.sf)
+        k = np.broadcast_to(synth.bicubic_psf_x4(), (B, 1, 25, 25)).copy()
+    else:
+        gen = mask_generator(config.mask_type, config.mask_len_range, config.mask_prob_range)
+        mask = np.concatenate([gen((1, 3, H, W)) for _ in range(B)], 0)
+        y = gt * mask
+    y = y * 2 - 1
+    y = y + np.random.normal(0, config.noise_level_img * 2, y.shape)
+    y = (y / 2 + 0.5).astype(np.float32)
+    if mask is not None:
+        y = (y * mask).astype(np.float32)
+    return y, k, mask
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--opt", type=str, required=True, help="Path to option YAML file.")
+    ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic images instead of the testset")
+    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--max-sweeps", type=int, default=0)
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
+    config = parse_config(args.opt)
+    np.random.seed(config.seed)
+    eng = Engine(args.device)
+
+    model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
+                        num_channels=128, num_res_blocks=1, attention_resolutions="16") \
+        if config.model_name == "diffusion_ffhq_10m" else \
+        dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
+             num_channels=256, num_res_blocks=2, attention_resolutions="8,16,32")
+    margs = utils_model.create_argparser(model_config).parse_args([])
+    model, diffusion = script_util.create_model_and_diffusion(
+        **script_util.args_to_dict(margs, script_util.model_and_diffusion_defaults().keys()), engine=eng)
+    if os.path.exists(margs.model_path):
+        model.load_state_dict(weights.load_checkpoint(margs.model_path))
+    else:
+        log.info("checkpoint %s not found: using synthetic weights (results are not meaningful images)", margs.model_path)
+        model.load_state_dict(weights.synth_state_dict("ffhq" if config.model_name == "diffusion_ffhq_10m" else "imagenet256"))
+
+    imgs, names = load_images(config, args.synthetic)
+    use_graph = bool(config.get("engine_graph", True))
+    noise = config.get("engine_noise", "device")
+    results = []
+    for si, (lambda_, zeta) in enumerate(sweeps(config)):
+        if args.max_sweeps and si >= args.max_sweeps:
+            break
+        cfg = loop_config(config, lambda_, zeta)
+        log.info("eta:%s, zeta:%s, lambda:%s, guidance_scale:%s", config.eta, zeta, lambda_, config.guidance_scale)
+        psnrs, t0, n = [], time.time(), 0
+        for i0 in range(0, len(imgs), config.batch_size):
+            gt = imgs[i0:i0 + config.batch_size]
+            y, k, mask = degrade(config, gt, i0)
+            nf = None
+            if noise == "host":
+                import torch
+                g = torch.Generator().manual_seed(config.seed)
+                nf = lambda shape: torch.randn(tuple(shape), generator=g).numpy()
+            out = restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source=noise, noise_fn=nf, seed=config.seed,
+                                        image_offset=i0, use_graph=use_graph,
+                                        skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False))).numpy()
+            p = restore.psnr_batch(out * 2 - 1, gt * 2 - 1)
+            psnrs.append(p * len(gt))
+            n += len(gt)
+            log.info("batch%4d--> PSNR: %.4fdB", i0 // config.batch_size + 1, p)
+        dt = time.time() - t0
+        log.info("-----------> Average PSNR(RGB) of (%s) scale factor: (%d), sigma: (%.3f): %.4f dB  [%.2f images/s]",
+                 config.testset_name, config.sf, config.noise_level_model, sum(psnrs) / n, n / dt)
+        results.append(sum(psnrs) / n)
+    eng.close()
+    return results
+
+
+if __name__ == "__main__":
+    main()

@@ -118,3 +118,24 @@ def test_product_weight_schema_equals_oracle_and_reference():
     b = uo.synth_state_dict(uo.tiny_hp(), 0)
     for k in a:
         np.testing.assert_array_equal(a[k], b[k].numpy())
+
+
+def test_yaml_driver_accepts_reference_style_configs(tmp_path):
+    """The driver's config surface: same flat keys as the reference's configs/*.yaml, same derived fields and sweeps."""
+    from diffpir_amd import main_ddpir as drv
+    ref_dir = "/root/reference/configs"
+    paths = [os.path.join(ROOT, "configs", "engine_example.yaml")]
+    if os.path.isdir(ref_dir):
+        paths += [os.path.join(ref_dir, f) for f in ("deblur.yaml", "inpaint.yaml", "sisr.yaml")]
+    for p in paths:
+        c = drv.parse_config(p)
+        lam, zeta = drv.sweeps(c)[0]
+        cfg = drv.loop_config(c, lam, zeta)
+        cfg.check_supported()
+        assert cfg.sigma == max(0.001, c.noise_level_img)
+        if c.task == "deblur":
+            assert (lam, zeta) == (c.lambda_ * 7, c.zeta * 3) and cfg.engine_task() == 0
+        if c.task == "sr":
+            assert len(drv.sweeps(c)) == 11 and cfg.engine_task() == 1
+        if c.task == "inpaint":
+            assert cfg.engine_task() == 2 and cfg.iter_num == 20
