@@ -40,10 +40,10 @@ struct ConvK {
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
 
 template <int KS, int KC, int WAVES_CO, int WCO, int WPX, int MODE>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
+__global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
     constexpr int TAPS = KS * KS;
     constexpr int BCO = WAVES_CO * WCO * 32;
-    constexpr int NP = 2;   // activation-tile positions handled per thread (chs <= 512)
+    constexpr int NP = (KS == 3) ? 2 : 1;   // activation-tile positions per thread (3x3 patch <= 512, 1x1 patch <= 128)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* lds_w = smem;                       // [TAPS][KC][BCO]
     float4* lds_prm = reinterpret_cast<float4*>(smem + TAPS * KC * BCO);   // [2][KC][8] GroupNorm/FiLM params
@@ -238,22 +238,41 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvK p) {
         }
         __syncthreads();
         if (c0 + KC < c_end) load_chunk(c0 + KC);
-        // ---- MFMA over taps x channel pairs
+        // ---- MFMA over taps x channel pairs.  Operands are read from LDS one STAGE (2 k-steps = 8 MFMAs per
+        // wave, ~500 cycles) ahead into a second register set, so ds_read latency never sits in front of an MFMA
+        // (the compiler's own schedule re-used one A register pair and waited lgkmcnt(0) every 4 MFMAs).
+        {
+            constexpr int KSTEPS = KC / 2;
+            constexpr int NSTEP = TAPS * KSTEPS;
+            constexpr int SG = 2;                       // k-steps per stage (8 MFMAs per wave, ~500 cycles of cover)
+            constexpr int NSTAGE = NSTEP / SG;
+            static_assert(NSTEP % SG == 0, "stage size must divide the step count");
+            float a_op[2][SG][WCO], b_op[2][SG][WPX];
+            auto load_stage = [&](int stage, int buf) {
 #pragma unroll
-        for (int tap = 0; tap < TAPS; ++tap) {
-            const int toff = (KS == 3) ? (tap / 3) * LW + (tap % 3) : 0;
+                for (int q = 0; q < SG; ++q) {
+                    const int f = stage * SG + q;
+                    const int tap = f / KSTEPS, kk = f % KSTEPS;
+                    const int toff = (KS == 3) ? (tap / 3) * LW + (tap % 3) : 0;
 #pragma unroll
-            for (int kk = 0; kk < KC / 2; ++kk) {
-                float a[WCO], b[WPX];
+                    for (int i = 0; i < WCO; ++i) a_op[buf][q][i] = lds_w[(tap * KC + 2 * kk) * BCO + aoff + i * 32];
 #pragma unroll
-                for (int i = 0; i < WCO; ++i) a[i] = lds_w[(tap * KC + 2 * kk) * BCO + aoff + i * 32];
+                    for (int j = 0; j < WPX; ++j) b_op[buf][q][j] = lds_x[(2 * kk) * p.chs + boff[j] + toff];
+                }
+            };
+            load_stage(0, 0);
 #pragma unroll
-                for (int j = 0; j < WPX; ++j) b[j] = lds_x[(2 * kk) * p.chs + boff[j] + toff];
+            for (int st = 0; st < NSTAGE; ++st) {
+                if (st + 1 < NSTAGE) load_stage(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < WCO; ++i)
+                for (int q = 0; q < SG; ++q)
 #pragma unroll
-                    for (int j = 0; j < WPX; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], b[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                        for (int j = 0; j < WPX; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_op[st & 1][q][i], b_op[st & 1][q][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
@@ -405,9 +424,9 @@ Status launch_conv(hipStream_t s, const ConvArgs& a) {
         if (a.Cout > 32) return launch_cfg<3, 8, 1, 2, 1>(s, k);
         return launch_cfg<3, 8, 1, 1, 1>(s, k);
     } else {
-        if (a.Cout > 64) return launch_cfg<1, 16, 2, 2, 2>(s, k);
-        if (a.Cout > 32) return launch_cfg<1, 16, 1, 2, 1>(s, k);
-        return launch_cfg<1, 16, 1, 1, 1>(s, k);
+        if (a.Cout > 64) return launch_cfg<1, 32, 2, 2, 2>(s, k);
+        if (a.Cout > 32) return launch_cfg<1, 32, 1, 2, 1>(s, k);
+        return launch_cfg<1, 32, 1, 1, 1>(s, k);
     }
 }
 
