@@ -595,6 +595,43 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     return DPIR_OK;
 }
 
+// ------------------------------------------------------------------------------------------ debug bench
+// Times one convolution shape in isolation (synthetic operands already on the device), optionally with parts of
+// the kernel disabled (ConvArgs::dbg ablation bits).  Not part of the product path; declared in diffpir_debug.h.
+int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int ks, int mode, int with_prm,
+                          int dbg, int iters, double* ms_out) {
+    if (!e || !ms_out || iters <= 0) return DPIR_ERR_INVALID;
+    (void)hipSetDevice(e->device);
+    int Hs = mode == 1 ? H / 2 : (mode == 2 ? H * 2 : H), Ws = mode == 1 ? W / 2 : (mode == 2 ? W * 2 : W);
+    int taps = ks * ks, coutp = round_up(Cout, 64), cinp = round_up(Cin, 16);
+    float *x = nullptr, *w = nullptr, *bias = nullptr, *out = nullptr, *partial = nullptr; float4* prm = nullptr;
+    API_TRY(e, e->ws.getT("dbg#x", (size_t)B * Cin * Hs * Ws, &x));
+    API_TRY(e, e->ws.getT("dbg#w", (size_t)cinp * taps * coutp, &w));
+    API_TRY(e, e->ws.getT("dbg#b", (size_t)coutp, &bias));
+    API_TRY(e, e->ws.getT("dbg#o", (size_t)B * Cout * H * W, &out));
+    API_TRY(e, e->ws.getT("dbg#prm", (size_t)B * Cin, &prm));
+    API_TRY(e, e->ws.getT("conv#partial", (size_t)16 * 1024 * 1024, &partial));
+    API_TRY(e, launch_randn(e->stream, x, 1, 1, 0, 1, (size_t)B * Cin * Hs * Ws));
+    API_TRY(e, launch_randn(e->stream, w, 2, 1, 0, 1, (size_t)cinp * taps * coutp));
+    API_TRY(e, launch_randn(e->stream, bias, 3, 1, 0, 1, (size_t)coutp));
+    API_TRY(e, launch_randn(e->stream, reinterpret_cast<float*>(prm), 4, 1, 0, 1, (size_t)B * Cin * 4));
+    ConvArgs a;
+    a.src.a = x; a.src.ca = Cin; a.src.Hs = Hs; a.src.Ws = Ws; a.src.mode = mode; a.src.prm = with_prm ? prm : nullptr;
+    a.w = w; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.CoutP = coutp; a.H = H; a.W = W; a.ks = ks;
+    a.partial = partial; a.partial_capacity = (size_t)16 * 1024 * 1024; a.dbg = dbg;
+    API_TRY(e, launch_conv(e->stream, a));
+    hipEvent_t e0, e1;
+    API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1));
+    API_HIP(e, hipEventRecord(e0, e->stream));
+    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv(e->stream, a));
+    API_HIP(e, hipEventRecord(e1, e->stream));
+    API_HIP(e, hipEventSynchronize(e1));
+    float ms = 0; API_HIP(e, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return DPIR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ profiling
 int dpir_prof_enable(dpir_engine* e, int on) {
     if (!e) return DPIR_ERR_INVALID;

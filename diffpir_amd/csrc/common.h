@@ -106,6 +106,7 @@ struct ConvArgs {
     int ks = 3;                   // 3 or 1
     float* partial = nullptr;     // split-K slab (optional) and its capacity in floats
     size_t partial_capacity = 0;
+    int dbg = 0;                  // ablation bits (debug bench only)
 };
 Status launch_conv(hipStream_t s, const ConvArgs& a);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -60,15 +60,17 @@ Status upload(dpir_engine* e, const float* host, size_t n, float** dev) {
     return Status{};
 }
 
-// OIHW (or OI1 for conv1d) -> [Cin][taps][CoutP]
+// OIHW (or OI1 for conv1d) -> [CinP][taps][CoutP], zero padded: CinP % 16 == 0, CoutP % 64 == 0 (conv2.hip's LDS-DMA
+// copies whole K chunks and 64-channel column blocks without bounds checks)
 Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int cin, int cout, int ks, bool one_d, ConvW* out) {
     const float *w = nullptr, *b = nullptr;
     std::vector<int64_t> shape = one_d ? std::vector<int64_t>{cout, cin, 1} : std::vector<int64_t>{cout, cin, ks, ks};
     DPIR_TRY(wm.find(p + ".weight", shape, &w));
     DPIR_TRY(wm.find(p + ".bias", {cout}, &b));
     int taps = ks * ks;
-    int coutp = round_up(cout, 32);
-    std::vector<float> packed((size_t)cin * taps * coutp, 0.f);
+    int coutp = round_up(cout, 64);
+    int cinp = round_up(cin, 16);
+    std::vector<float> packed((size_t)cinp * taps * coutp, 0.f);
     for (int co = 0; co < cout; ++co)
         for (int ci = 0; ci < cin; ++ci)
             for (int t = 0; t < taps; ++t)
