@@ -45,6 +45,22 @@ Status dpir_engine::fft_plan(int N, FftPlan* out) {
     return Status{};
 }
 
+Status dpir_engine::fft2_table(int N, const float2** out) {
+    auto it = fft2_tw.find(N);
+    if (it != fft2_tw.end()) { *out = it->second; return Status{}; }
+    std::vector<float2> tw(N);
+    for (int m = 0; m < N; ++m) {
+        double a = -2.0 * M_PI * (double)m / (double)N;
+        tw[m] = make_float2((float)cos(a), (float)sin(a));
+    }
+    void* d = nullptr;
+    DPIR_HIP(hipMalloc(&d, tw.size() * sizeof(float2)));
+    DPIR_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
+    fft2_tw[N] = reinterpret_cast<float2*>(d);
+    *out = fft2_tw[N];
+    return Status{};
+}
+
 Status dpir_engine::resizer(int in_len, int sf, ResizerTab* out) {
     auto key = std::make_pair(in_len, sf);
     auto it = resizers.find(key);
@@ -93,6 +109,7 @@ void dpir_destroy(dpir_engine* e) {
     unet_free(e);
     e->ws.release();
     for (auto& kv : e->fft_plans) (void)hipFree(kv.second.tw);
+    for (auto& kv : e->fft2_tw) (void)hipFree(kv.second);
     for (auto& kv : e->resizers) { (void)hipFree(kv.second.w); (void)hipFree(kv.second.idx); }
     for (void* p : e->user_allocs) (void)hipFree(p);
     e->invalidate_graphs();
@@ -214,11 +231,26 @@ double dpir_unet_flops_class(dpir_engine* e, int H, int W, int cls) { return e ?
 // ------------------------------------------------------------------------------------------ FFT prox
 static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, ProxState* st) {
     if (sf < 1 || H % sf || W % sf) return invalid("pre_calculate: image size not divisible by sf");
+    hipStream_t s = e->stream;
+    ProfScope ps(&e->prof, PC_FFT);
+    if (st->half) {
+        // half-spectrum register-FFT path (fft2.hip): FB = rfft2(p2o-embedded PSF), FBFy = conj(FB) * rfft2(y)
+        const float2* tw = nullptr;
+        DPIR_TRY(e->fft2_table(W, &tw));
+        float* psf = nullptr;
+        DPIR_TRY(e->ws.getT("prox#psf", (size_t)B * H * W, &psf));
+        SolveArgs none{};
+        DPIR_TRY(launch_psf_embed_real(s, k, kh, kw, psf, B, H, W));
+        DPIR_TRY(launch_rfft_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, W));
+        DPIR_TRY(launch_cfft_cols(s, tw, st->FB, none, false, B, H));
+        DPIR_TRY(launch_rfft_rows(s, tw, y, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, W));
+        DPIR_TRY(launch_cfft_cols(s, tw, st->FBFy, none, false, B * 3, H));
+        DPIR_TRY(launch_precalc_finish2(s, st->FB, st->FBFy, st->F2B, B, (size_t)H * st->WP));
+        return Status{};
+    }
     FftPlan ph, pw;
     DPIR_TRY(e->fft_plan(H, &ph));
     DPIR_TRY(e->fft_plan(W, &pw));
-    hipStream_t s = e->stream;
-    ProfScope ps(&e->prof, PC_FFT);
     DPIR_TRY(launch_psf_embed(s, k, kh, kw, st->FB, B, H, W));
     DPIR_TRY(launch_fft_rows(s, pw, st->FB, nullptr, 1.f, 0.f, B, H, W, false));
     DPIR_TRY(launch_fft_cols(s, ph, st->FB, B, H, W, false));
@@ -230,8 +262,10 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
 }
 
 static Status prox_alloc(int sf, int B, int H, int W, ProxState* st) {
-    size_t hw = (size_t)H * W;
     st->B = B; st->H = H; st->W = W; st->sf = sf;
+    st->half = fft2_supported(H, W, sf);
+    st->WP = st->half ? fft2_padded_width(W) : W;
+    size_t hw = (size_t)H * st->WP;
     if (hipMalloc((void**)&st->FB, B * hw * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&st->F2B, B * hw * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&st->FBFy, 3 * B * hw * sizeof(float2)) != hipSuccess)
@@ -275,6 +309,28 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
     const ProxState& st = p->st;
     size_t hw = (size_t)st.H * st.W;
     size_t planes = which == 2 ? (size_t)3 * st.B : (size_t)st.B;
+    if (st.half) {
+        if (which < 0 || which > 2) return fail(e, invalid("dpir_prox_read: which must be 0, 1 or 2"));
+        size_t esz = which == 1 ? sizeof(float) : sizeof(float2);
+        if (cap_bytes < planes * hw * esz) return fail(e, invalid("dpir_prox_read: destination too small"));
+        size_t shw = (size_t)st.H * st.WP;
+        std::vector<char> tmp(planes * shw * esz);
+        const void* src = which == 0 ? (const void*)st.FB : (which == 1 ? (const void*)st.F2B : (const void*)st.FBFy);
+        int rc = dpir_d2h(e, tmp.data(), src, tmp.size());
+        if (rc != DPIR_OK) return rc;
+        // natural[u][v] = stored[u][v] for v <= W/2, conj(stored[(H-u)%H][W-v]) beyond (Hermitian spectra of real signals)
+        for (size_t pl = 0; pl < planes; ++pl)
+            for (int u = 0; u < st.H; ++u)
+                for (int v = 0; v < st.W; ++v) {
+                    bool mir = v > st.W / 2;
+                    int su = mir ? (st.H - u) % st.H : u, sv = mir ? st.W - v : v;
+                    const char* sp = tmp.data() + (pl * shw + (size_t)su * st.WP + sv) * esz;
+                    char* dp = reinterpret_cast<char*>(host_dst) + (pl * hw + (size_t)u * st.W + v) * esz;
+                    memcpy(dp, sp, esz);
+                    if (mir && which != 1) reinterpret_cast<float*>(dp)[1] = -reinterpret_cast<float*>(dp)[1];
+                }
+        return DPIR_OK;
+    }
     size_t esz = which == 1 ? sizeof(float) : sizeof(float2);
     const void* src = which == 0 ? (const void*)st.FB : (which == 1 ? (const void*)st.F2B : (const void*)st.FBFy);
     if (which < 0 || which > 2) return fail(e, invalid("dpir_prox_read: which must be 0, 1 or 2"));
@@ -297,6 +353,20 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
 static Status data_solution_impl(dpir_engine* e, const ProxState& st, const float* x, float pa, float pb, float alpha, float* out,
                                  float oa, float ob, const float* blend_base, float g, const StepDev* sp = nullptr) {
     if (!sp && !(alpha > 0.f)) return invalid("data_solution: alpha must be > 0");
+    if (st.half) {
+        const float2* tw = nullptr;
+        DPIR_TRY(e->fft2_table(st.W, &tw));
+        float2* hbuf = nullptr;
+        DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)st.B * 3 * st.H * st.WP, &hbuf));
+        hipStream_t s2 = e->stream;
+        ProfScope ps2(&e->prof, PC_FFT);
+        DPIR_TRY(launch_rfft_rows(s2, tw, x, pa, pb, alpha, sp, hbuf, st.B * 3, st.W));
+        SolveArgs a2{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp};
+        DPIR_TRY(launch_cfft_cols(s2, tw, hbuf, a2, true, st.B * 3, st.H));
+        float sc = 1.0f / ((float)st.H * (float)st.W);
+        DPIR_TRY(launch_irfft_rows(s2, tw, hbuf, out, sc, oa, ob, (blend_base && g != 1.0f) ? blend_base : nullptr, g, st.B * 3, st.W));
+        return Status{};
+    }
     FftPlan ph, pw;
     DPIR_TRY(e->fft_plan(st.H, &ph));
     DPIR_TRY(e->fft_plan(st.W, &pw));

@@ -62,4 +62,15 @@ Status launch_psf_embed(hipStream_t s, const float* k, int kh, int kw, float2* o
 Status launch_upsample_embed(hipStream_t s, const float* y, int sf, float2* out, int P, int h, int w);
 Status launch_precalc_finish(hipStream_t s, const float2* FB, float2* FBFy_inout, float* F2B, int B, int H, int W);
 
+// fft2.hip: half-spectrum register FFT path (sf = 1, N = 64 / 256).  twN = W_N^m table (N entries, device)
+bool fft2_supported(int H, int W, int sf);
+int fft2_padded_width(int W);
+Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
+                        float2* out, int P, int N);
+Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
+                         const float* blend, float g, int P, int N);
+Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N);
+Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw);
+Status launch_psf_embed_real(hipStream_t s, const float* k, int kh, int kw, float* out, int B, int H, int W);
+
 }  // namespace dpir

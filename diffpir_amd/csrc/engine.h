@@ -60,6 +60,8 @@ struct TapInfo { const float* p; size_t numel; };
 struct ProxState {   // dpir_prox
     int B = 0, H = 0, W = 0, sf = 1;
     float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
+    bool half = false;     // true: natural-order half spectrum [.., H, WP] (fft2.hip); false: bit-reversed full c2c (fft.hip)
+    int WP = 0;            // stored row length (complex elements)
 };
 
 struct ResizerTab { int in_len = 0, out_len = 0, taps = 0; float* w = nullptr; int* idx = nullptr; };
@@ -77,6 +79,7 @@ struct dpir_engine {
     dpir::Workspace ws;          // UNet activations + loop state
     std::map<std::string, dpir::TapInfo> taps;
     std::map<int, dpir::FftPlan> fft_plans;
+    std::map<int, float2*> fft2_tw;              // W_N^m tables (N entries) for fft2.hip
     std::map<std::pair<int, int>, dpir::ResizerTab> resizers;   // (in_len, sf)
     std::vector<void*> user_allocs;
     bool collect_taps = true;
@@ -89,6 +92,7 @@ struct dpir_engine {
     }
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);
+    dpir::Status fft2_table(int N, const float2** out);
     dpir::Status resizer(int in_len, int sf, dpir::ResizerTab* out);
 };
 

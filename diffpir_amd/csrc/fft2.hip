@@ -1,0 +1,335 @@
+// fft2: half-spectrum, register-resident FFT path of the data-fidelity prox for sf = 1 (deblurring, the headline
+// configuration) at N = 64 / 256.  Replaces the same reference lines as fft.hip (utils/utils_sisr.py:65-95); the
+// radix-2 / full-c2c kernels of fft.hip remain the general path (sf > 1, other sizes).
+//
+// Structure (per batch of P = 3B image planes, HBM-bound):
+//   rfft_rows   : two REAL rows are packed into one complex transform (z = a + i b), N = Ra x Rb two-pass FFT held in
+//                 registers (16 x 16 at N = 256: one LDS exchange between the passes), un-packed with the Hermitian
+//                 identity into two half-spectrum rows (N/2+1 columns, padded to a multiple of the strip width);
+//   cfft_cols   : a strip of columns per workgroup: forward FFT -> closed-form spectral solve -> inverse FFT without
+//                 leaving registers (the output distribution of the forward pass-2 IS the input distribution of the
+//                 inverse pass-1), two LDS exchanges in total;
+//   irfft_rows  : Hermitian re-packing of two half-spectrum rows into one complex inverse transform, real / imag parts
+//                 are the two output rows; epilogue x*2-1 and the guidance blend.
+// Algorithmic HBM bytes per image per step at 256^2: 2.50 MB; the padded half-spectrum intermediate
+// (3 x 256 x 144 x 8 B = 0.88 MB, written once and read once by each neighbour kernel) stays in L2 / Infinity Cache.
+#include "common.h"
+#include "elem.h"
+
+namespace dpir {
+
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ float2 cmul2(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cmulc2(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
+template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) {   // a * (-i) forward, a * (+i) inverse
+    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
+}
+
+template <bool INV> __device__ __forceinline__ void fft4(float2& a0, float2& a1, float2& a2, float2& a3) {
+    float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_mi<INV>(csub(a1, a3));
+    a0 = cadd(s0, s2); a2 = csub(s0, s2); a1 = cadd(s1, s3); a3 = csub(s1, s3);
+}
+template <bool INV> __device__ __forceinline__ void fft2p(float2& a0, float2& a1) {
+    float2 t = a0; a0 = cadd(t, a1); a1 = csub(t, a1);
+}
+
+// in-register R-point FFT, natural order in and out (R = 8 or 16)
+template <int R, bool INV> struct RegFFT;
+template <bool INV> struct RegFFT<16, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[16]) {
+        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
+        // step 1: 4-point FFTs over n1 for each n2 (x[4 n1 + n2])
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) fft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
+        // now v[4 k1 + n2] = t[k1][n2]; twiddle W16^(n2 k1) (conjugated for the inverse)
+        const float2 w[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
+#pragma unroll
+        for (int k1 = 1; k1 < 4; ++k1)
+#pragma unroll
+            for (int n2 = 1; n2 < 4; ++n2) {
+                float2 tw = w[k1 * n2];
+                v[4 * k1 + n2] = INV ? cmulc2(v[4 * k1 + n2], tw) : cmul2(v[4 * k1 + n2], tw);
+            }
+        // step 2: 4-point FFTs over n2 for each k1 -> X[k1 + 4 k2] at position 4 k1 + k2
+#pragma unroll
+        for (int k1 = 0; k1 < 4; ++k1) fft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
+        // transpose 4x4 to natural order: out[k1 + 4 k2] <- v[4 k1 + k2]
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = a + 1; b < 4; ++b) { float2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
+    }
+};
+template <bool INV> struct RegFFT<8, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[8]) {
+        const float h = 0.70710678118654752f;
+        // 8 = 2 x 4: n = 4 n1 + n2 (n1 < 2, n2 < 4), k = k1 + 2 k2
+#pragma unroll
+        for (int n2 = 0; n2 < 4; ++n2) fft2p<INV>(v[n2], v[4 + n2]);       // t[k1][n2] at v[4 k1 + n2]
+        const float2 w[4] = {{1.f, 0.f}, {h, -h}, {0.f, -1.f}, {-h, -h}};    // W8^(n2) for k1 = 1
+#pragma unroll
+        for (int n2 = 1; n2 < 4; ++n2) v[4 + n2] = INV ? cmulc2(v[4 + n2], w[n2]) : cmul2(v[4 + n2], w[n2]);
+        fft4<INV>(v[0], v[1], v[2], v[3]);                                  // X[0 + 2 k2] at v[k2]
+        fft4<INV>(v[4], v[5], v[6], v[7]);                                  // X[1 + 2 k2] at v[4 + k2]
+        float2 o[8];
+#pragma unroll
+        for (int k2 = 0; k2 < 4; ++k2) { o[2 * k2] = v[k2]; o[2 * k2 + 1] = v[4 + k2]; }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) v[i] = o[i];
+    }
+};
+
+// Two-pass N = R*R transform for one "slot" (R cooperating threads, t = 0..R-1).
+//   pass 1 in : thread t holds x[R n1 + t], n1 = 0..R-1            (stride-R elements, offset t)
+//   pass 2 out: thread t holds X[t + R k2], k2 = 0..R-1            (same distribution -> inverse can start from it)
+// xch: this slot's LDS exchange area of R*(R+1) float2; twN: table of W_N^m (cos, -sin), m < N, in LDS.
+template <int R, bool INV>
+__device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch, const float2* twN) {
+    RegFFT<R, INV>::run(v);                                   // over n1 -> Y[k1] for n2 = t
+#pragma unroll
+    for (int k1 = 0; k1 < R; ++k1) {
+        float2 tw = twN[(t * k1) & (R * R - 1)];
+        float2 y = INV ? cmulc2(v[k1], tw) : cmul2(v[k1], tw);
+        xch[k1 * (R + 1) + t] = y;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int n2 = 0; n2 < R; ++n2) v[n2] = xch[t * (R + 1) + n2];   // thread k1 = t reads Y[k1][n2]
+    __syncthreads();
+    RegFFT<R, INV>::run(v);                                   // over n2 -> X[t + R k2]
+}
+
+// ------------------------------------------------------------------------------------------------ rows forward
+// One slot = one PAIR of real rows.  grid: ceil(total_rows/2 / SLOTS); block 256 = SLOTS*R threads.
+template <int R>
+__global__ __launch_bounds__(256) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
+                                                         int WP, size_t total_rows, const float2* tw) {
+    constexpr int N = R * R, SLOTS = 256 / R;
+    extern __shared__ __attribute__((aligned(16))) float2 sm2[];
+    float2* twN = sm2;                                  // [N]
+    float2* xch = sm2 + N;                              // [SLOTS][R*(R+1)]
+    float2* zbuf = xch + SLOTS * R * (R + 1);           // [SLOTS][N+1]  natural-order Z of each slot
+    if (sp) pm = sp->tau;
+    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    const int slot = threadIdx.x / R, t = threadIdx.x % R;
+    const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
+    const size_t ra = 2 * pair, rb = 2 * pair + 1;
+    const bool va = ra < total_rows, vb = rb < total_rows;
+    float2 v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) {
+        int n = R * n1 + t;
+        float a = va ? (x[ra * N + n] * pa + pb) * pm : 0.f;
+        float b = vb ? (x[rb * N + n] * pa + pb) * pm : 0.f;
+        v[n1] = make_float2(a, b);
+    }
+    __syncthreads();
+    fft_two_pass<R, false>(v, t, xch + slot * R * (R + 1), twN);
+    float2* z = zbuf + slot * (N + 1);
+#pragma unroll
+    for (int k2 = 0; k2 < R; ++k2) z[t + R * k2] = v[k2];
+    __syncthreads();
+    // un-pack: A[k] = (Z[k] + conj(Z[N-k]))/2, B[k] = (Z[k] - conj(Z[N-k]))/(2i), k = 0..N/2; zero the padding columns
+    for (int k = t; k < WP; k += R) {
+        float2 A = make_float2(0.f, 0.f), Bv = make_float2(0.f, 0.f);
+        if (k <= N / 2) {
+            float2 zk = z[k], zn = z[(N - k) & (N - 1)];
+            zn.y = -zn.y;
+            A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
+            float2 d = csub(zk, zn);
+            Bv = make_float2(0.5f * d.y, -0.5f * d.x);
+        }
+        if (va) out[ra * WP + k] = A;
+        if (vb) out[rb * WP + k] = Bv;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ rows inverse
+template <int R>
+__global__ __launch_bounds__(256) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
+                                                          const float* blend_base, float g, int WP, size_t total_rows, const float2* tw) {
+    constexpr int N = R * R, SLOTS = 256 / R;
+    extern __shared__ __attribute__((aligned(16))) float2 sm2[];
+    float2* twN = sm2;
+    float2* xch = sm2 + N;
+    float2* zbuf = xch + SLOTS * R * (R + 1);
+    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    const int slot = threadIdx.x / R, t = threadIdx.x % R;
+    const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
+    const size_t ra = 2 * pair, rb = 2 * pair + 1;
+    const bool va = ra < total_rows, vb = rb < total_rows;
+    float2* z = zbuf + slot * (N + 1);
+    // Hermitian re-packing: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
+    for (int k = t; k <= N / 2; k += R) {
+        float2 A = va ? in[ra * WP + k] : make_float2(0.f, 0.f);
+        float2 Bv = vb ? in[rb * WP + k] : make_float2(0.f, 0.f);
+        z[k] = make_float2(A.x - Bv.y, A.y + Bv.x);
+        if (k > 0 && k < N / 2) z[N - k] = make_float2(A.x + Bv.y, -A.y + Bv.x);
+    }
+    __syncthreads();
+    float2 v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = z[R * n1 + t];
+    __syncthreads();
+    fft_two_pass<R, true>(v, t, xch + slot * R * (R + 1), twN);
+#pragma unroll
+    for (int k2 = 0; k2 < R; ++k2) {
+        int n = t + R * k2;
+        if (va) {
+            size_t gi = ra * N + n;
+            float val = (v[k2].x * scale) * oa + ob;
+            if (blend_base) { float b0 = blend_base[gi]; val = b0 + g * (val - b0); }
+            out[gi] = val;
+        }
+        if (vb) {
+            size_t gi = rb * N + n;
+            float val = (v[k2].y * scale) * oa + ob;
+            if (blend_base) { float b0 = blend_base[gi]; val = b0 + g * (val - b0); }
+            out[gi] = val;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ columns
+// A strip of CS = 256/R columns per workgroup; thread = (column c, t).  MODE 0: forward only; MODE 2: forward ->
+// solve (sf = 1: FX = (FR - conj(FB) * (FB*FR)/(F2B+alpha)) / alpha, FR = FBFy + F(alpha x)) -> inverse.
+template <int R, int MODE>
+__global__ __launch_bounds__(256) void cfft_cols_kernel(float2* buf, SolveArgs a, int WP, const float2* tw) {
+    constexpr int N = R * R, CS = 256 / R;
+    extern __shared__ __attribute__((aligned(16))) float2 sm2[];
+    float2* twN = sm2;
+    float2* xch = sm2 + N;                              // [CS][R*(R+1)+1]  (+1: lanes of a wave walk the slots)
+    constexpr int XST = R * (R + 1) + 1;
+    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    const int c = threadIdx.x % CS, t = threadIdx.x / CS;     // lanes walk the strip's columns: 128-byte row segments
+    const int strips = WP / CS;
+    const int plane = blockIdx.x / strips;
+    const int col = (blockIdx.x - plane * strips) * CS + c;
+    float2* base = buf + (size_t)plane * N * WP + col;
+    float2 v[R];
+#pragma unroll
+    for (int n1 = 0; n1 < R; ++n1) v[n1] = base[(size_t)(R * n1 + t) * WP];
+    __syncthreads();
+    fft_two_pass<R, false>(v, t, xch + c * XST, twN);
+    if (MODE == 2) {
+        float alpha = a.sp ? a.sp->tau : a.alpha;
+        const int n_img = plane / 3;
+        const float2* FB = a.FB + (size_t)n_img * N * WP + col;
+        const float* F2B = a.F2B + (size_t)n_img * N * WP + col;
+        const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
+#pragma unroll
+        for (int k2 = 0; k2 < R; ++k2) {
+            size_t off = (size_t)(t + R * k2) * WP;
+            float2 fr = cadd(FBFy[off], v[k2]);
+            float2 fb = FB[off];
+            float2 x1 = cmul2(fb, fr);
+            float den = F2B[off] + alpha;
+            float2 q = make_float2(x1.x / den, x1.y / den);
+            float2 tq = cmulc2(q, fb);                          // conj(FB) * q
+            v[k2] = make_float2((fr.x - tq.x) / alpha, (fr.y - tq.y) / alpha);
+        }
+        fft_two_pass<R, true>(v, t, xch + c * XST, twN);
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < R; ++k2) base[(size_t)(t + R * k2) * WP] = v[k2];
+}
+
+// FBFy <- conj(FB) * F(y); F2B = |FB|^2 on the padded half-spectrum layout
+__global__ void precalc_finish2_kernel(const float2* FB, float2* FBFy, float* F2B, size_t hw, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t p = i / hw, r = i - p * hw;
+        size_t b = p / 3;
+        float2 fb = FB[b * hw + r];
+        FBFy[i] = cmulc2(FBFy[i], fb);
+        if (p % 3 == 0) { float m = hypotf(fb.x, fb.y); F2B[b * hw + r] = m * m; }
+    }
+}
+// p2o embedding as a REAL image (natural order): out[y][x] = k[(y + kh/2) % H][(x + kw/2) % W] inside the PSF support
+__global__ void psf_embed_real_kernel(const float* k, int kh, int kw, float* out, int H, int W, size_t total) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        size_t b = i / ((size_t)H * W);
+        size_t r = i - b * (size_t)H * W;
+        int y = (int)(r / W), x = (int)(r - (size_t)y * W);
+        int ky = (y + kh / 2) % H, kx = (x + kw / 2) % W;
+        out[i] = (ky < kh && kx < kw) ? k[(b * kh + ky) * kw + kx] : 0.f;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ launchers
+bool fft2_supported(int H, int W, int sf) { return sf == 1 && H == W && (H == 256 || H == 64); }
+int fft2_padded_width(int W) { int cs = (W == 256) ? 16 : 32; return (W / 2 + 1 + cs - 1) / cs * cs; }
+
+template <int R>
+static size_t rows_lds() { return (size_t)(R * R + (256 / R) * R * (R + 1) + (256 / R) * (R * R + 1)) * sizeof(float2); }
+template <int R>
+static size_t cols_lds() { return (size_t)(R * R + (256 / R) * (R * (R + 1) + 1)) * sizeof(float2); }
+
+template <int R>
+static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
+                          const float2* tw) {
+    int WP = fft2_padded_width(N);
+    size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
+    constexpr int SLOTS = 256 / R;
+    auto fn = rfft_rows_kernel<R>;
+    static bool attr = false;
+    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(256), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
+                        float2* out, int P, int N) {
+    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN);
+}
+
+template <int R>
+static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
+                           int P, int N, const float2* tw) {
+    int WP = fft2_padded_width(N);
+    size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
+    constexpr int SLOTS = 256 / R;
+    auto fn = irfft_rows_kernel<R>;
+    static bool attr = false;
+    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(256), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
+                       rows, tw);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
+                         const float* blend, float g, int P, int N) {
+    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN)
+                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN);
+}
+
+template <int R, int MODE>
+static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P, int N, const float2* tw) {
+    int WP = fft2_padded_width(N);
+    constexpr int CS = 256 / R;
+    auto fn = cfft_cols_kernel<R, MODE>;
+    static bool attr = false;
+    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(256), cols_lds<R>(), s, buf, a, WP, tw);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N) {
+    if (N == 256) return solve ? cfft_cols_RM<16, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<16, 0>(s, buf, a, P, N, twN);
+    return solve ? cfft_cols_RM<8, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<8, 0>(s, buf, a, P, N, twN);
+}
+Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw) {
+    size_t total = (size_t)B * 3 * hw;
+    hipLaunchKernelGGL(precalc_finish2_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, FB, FBFy, F2B, hw, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_psf_embed_real(hipStream_t s, const float* k, int kh, int kw, float* out, int B, int H, int W) {
+    if (kh > H || kw > W) return invalid("PSF larger than the image");
+    size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(psf_embed_real_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k, kh, kw, out, H, W, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+}  // namespace dpir
