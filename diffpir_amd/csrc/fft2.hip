@@ -102,31 +102,45 @@ __device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch,
 
 // ------------------------------------------------------------------------------------------------ rows forward
 // One slot = one PAIR of real rows.  grid: ceil(total_rows/2 / SLOTS); block 256 = SLOTS*R threads.
-template <int R>
-__global__ __launch_bounds__(256) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
+template <int R, int THREADS>
+__global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
                                                          int WP, size_t total_rows, const float2* tw) {
-    constexpr int N = R * R, SLOTS = 256 / R;
+    constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;                                  // [N]
     float2* xch = sm2 + N;                              // [SLOTS][R*(R+1)]
-    float2* zbuf = xch + SLOTS * R * (R + 1);           // [SLOTS][N+1]  natural-order Z of each slot
+    float2* zbuf = xch + SLOTS * R * (R + 1);           // [SLOTS][N+4]  natural-order Z of each slot (also the load staging)
     if (sp) pm = sp->tau;
-    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
     const size_t ra = 2 * pair, rb = 2 * pair + 1;
     const bool va = ra < total_rows, vb = rb < total_rows;
+    // coalesced float4 loads of the block's 2*SLOTS rows into LDS, then the strided gather of the two-pass layout
+    float* stage = reinterpret_cast<float*>(zbuf);          // [2*SLOTS][N + 4] floats == SLOTS*(N+4) float2
+    {
+        const size_t row0 = (size_t)blockIdx.x * SLOTS * 2;
+        constexpr int V4 = N / 4;
+        for (int i = threadIdx.x; i < 2 * SLOTS * V4; i += THREADS) {
+            int r = i / V4, c4 = i - r * V4;
+            size_t row = row0 + r;
+            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < total_rows) q = *reinterpret_cast<const float4*>(x + row * N + c4 * 4);
+            *reinterpret_cast<float4*>(stage + r * (N + 4) + c4 * 4) = q;
+        }
+    }
+    __syncthreads();
     float2 v[R];
 #pragma unroll
     for (int n1 = 0; n1 < R; ++n1) {
         int n = R * n1 + t;
-        float a = va ? (x[ra * N + n] * pa + pb) * pm : 0.f;
-        float b = vb ? (x[rb * N + n] * pa + pb) * pm : 0.f;
-        v[n1] = make_float2(a, b);
+        float a = (stage[(2 * slot) * (N + 4) + n] * pa + pb) * pm;
+        float b = (stage[(2 * slot + 1) * (N + 4) + n] * pa + pb) * pm;
+        v[n1] = make_float2(va ? a : 0.f, vb ? b : 0.f);
     }
     __syncthreads();
     fft_two_pass<R, false>(v, t, xch + slot * R * (R + 1), twN);
-    float2* z = zbuf + slot * (N + 1);
+    float2* z = zbuf + slot * (N + 4);
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) z[t + R * k2] = v[k2];
     __syncthreads();
@@ -146,20 +160,20 @@ __global__ __launch_bounds__(256) void rfft_rows_kernel(const float* x, float pa
 }
 
 // ------------------------------------------------------------------------------------------------ rows inverse
-template <int R>
-__global__ __launch_bounds__(256) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
+template <int R, int THREADS>
+__global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
                                                           const float* blend_base, float g, int WP, size_t total_rows, const float2* tw) {
-    constexpr int N = R * R, SLOTS = 256 / R;
+    constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
     float2* xch = sm2 + N;
     float2* zbuf = xch + SLOTS * R * (R + 1);
-    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
     const size_t ra = 2 * pair, rb = 2 * pair + 1;
     const bool va = ra < total_rows, vb = rb < total_rows;
-    float2* z = zbuf + slot * (N + 1);
+    float2* z = zbuf + slot * (N + 4);
     // Hermitian re-packing: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
     for (int k = t; k <= N / 2; k += R) {
         float2 A = va ? in[ra * WP + k] : make_float2(0.f, 0.f);
@@ -194,14 +208,14 @@ __global__ __launch_bounds__(256) void irfft_rows_kernel(const float2* in, float
 // ------------------------------------------------------------------------------------------------ columns
 // A strip of CS = 256/R columns per workgroup; thread = (column c, t).  MODE 0: forward only; MODE 2: forward ->
 // solve (sf = 1: FX = (FR - conj(FB) * (FB*FR)/(F2B+alpha)) / alpha, FR = FBFy + F(alpha x)) -> inverse.
-template <int R, int MODE>
-__global__ __launch_bounds__(256) void cfft_cols_kernel(float2* buf, SolveArgs a, int WP, const float2* tw) {
-    constexpr int N = R * R, CS = 256 / R;
+template <int R, int MODE, int THREADS>
+__global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveArgs a, int WP, const float2* tw) {
+    constexpr int N = R * R, CS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
     float2* xch = sm2 + N;                              // [CS][R*(R+1)+1]  (+1: lanes of a wave walk the slots)
     constexpr int XST = R * (R + 1) + 1;
-    for (int i = threadIdx.x; i < N; i += 256) twN[i] = tw[i];
+    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int c = threadIdx.x % CS, t = threadIdx.x / CS;     // lanes walk the strip's columns: 128-byte row segments
     const int strips = WP / CS;
     const int plane = blockIdx.x / strips;
@@ -258,23 +272,25 @@ __global__ void psf_embed_real_kernel(const float* k, int kh, int kw, float* out
 
 // ------------------------------------------------------------------------------------------------ launchers
 bool fft2_supported(int H, int W, int sf) { return sf == 1 && H == W && (H == 256 || H == 64); }
-int fft2_padded_width(int W) { int cs = (W == 256) ? 16 : 32; return (W / 2 + 1 + cs - 1) / cs * cs; }
+int fft2_padded_width(int W) { int cs = (W == 256) ? 8 : 16; return (W / 2 + 1 + cs - 1) / cs * cs; }   // multiple of the column strip
 
+constexpr int ROW_THREADS = 64;    // small workgroups: at B = 16 the whole prox is ~40 MB, concurrency comes from block count
+constexpr int COL_THREADS = 128;
 template <int R>
-static size_t rows_lds() { return (size_t)(R * R + (256 / R) * R * (R + 1) + (256 / R) * (R * R + 1)) * sizeof(float2); }
+static size_t rows_lds() { return (size_t)(R * R + (ROW_THREADS / R) * R * (R + 1) + (ROW_THREADS / R) * (R * R + 4)) * sizeof(float2); }
 template <int R>
-static size_t cols_lds() { return (size_t)(R * R + (256 / R) * (R * (R + 1) + 1)) * sizeof(float2); }
+static size_t cols_lds() { return (size_t)(R * R + (COL_THREADS / R) * (R * (R + 1) + 1)) * sizeof(float2); }
 
 template <int R>
 static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
                           const float2* tw) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
-    constexpr int SLOTS = 256 / R;
-    auto fn = rfft_rows_kernel<R>;
+    constexpr int SLOTS = ROW_THREADS / R;
+    auto fn = rfft_rows_kernel<R, ROW_THREADS>;
     static bool attr = false;
     if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(256), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -288,11 +304,11 @@ static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float sc
                            int P, int N, const float2* tw) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
-    constexpr int SLOTS = 256 / R;
-    auto fn = irfft_rows_kernel<R>;
+    constexpr int SLOTS = ROW_THREADS / R;
+    auto fn = irfft_rows_kernel<R, ROW_THREADS>;
     static bool attr = false;
     if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(256), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
                        rows, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
@@ -306,11 +322,11 @@ Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, flo
 template <int R, int MODE>
 static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P, int N, const float2* tw) {
     int WP = fft2_padded_width(N);
-    constexpr int CS = 256 / R;
-    auto fn = cfft_cols_kernel<R, MODE>;
+    constexpr int CS = COL_THREADS / R;
+    auto fn = cfft_cols_kernel<R, MODE, COL_THREADS>;
     static bool attr = false;
     if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(256), cols_lds<R>(), s, buf, a, WP, tw);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), cols_lds<R>(), s, buf, a, WP, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
