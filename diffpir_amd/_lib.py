@@ -57,6 +57,7 @@ SIGNATURES = {
     "dpir_d2h": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dpir_d2d": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dpir_load_unet": (C.c_int, [C.c_void_p, C.POINTER(UNetDesc), C.POINTER(Tensor), C.c_int]),
+    "dpir_set_precision": (C.c_int, [C.c_void_p, C.c_int]),
     "dpir_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_model_fn_xstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),

@@ -186,6 +186,14 @@ static Status upload_ints(dpir_engine* e, const char* name, const int64_t* host,
     return Status{};
 }
 
+int dpir_set_precision(dpir_engine* e, int mode) {
+    if (!e) return DPIR_ERR_INVALID;
+    if (mode != 0 && mode != 1) return fail(e, invalid("dpir_set_precision: mode must be 0 (fp32 MFMA) or 1 (operand-split f16x3 MFMA)"));
+    if (e->net.loaded && mode != e->precision) return fail(e, Status{DPIR_ERR_STATE, "dpir_set_precision must be called before dpir_load_unet"});
+    e->precision = mode;
+    return DPIR_OK;
+}
+
 int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, const int64_t* y_host, float* out, int B, int H, int W) {
     if (!e || !x || !t_host || !out) return fail(e, invalid("dpir_unet_forward: null argument"));
     (void)hipSetDevice(e->device);
@@ -688,7 +696,17 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
     ConvArgs a;
     a.src.a = x; a.src.ca = Cin; a.src.Hs = Hs; a.src.Ws = Ws; a.src.mode = mode; a.src.prm = with_prm ? prm : nullptr;
     a.w = w; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.CoutP = coutp; a.H = H; a.W = W; a.ks = ks;
-    a.partial = partial; a.partial_capacity = (size_t)16 * 1024 * 1024; a.dbg = dbg;
+    a.partial = partial; a.partial_capacity = (size_t)16 * 1024 * 1024; a.dbg = dbg & ~64;
+    if (dbg & 64) {   // operand-split f16 path with synthetic split weights
+        std::vector<float> hw((size_t)Cout * Cin * taps);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
+        std::vector<uint16_t> w16;
+        a.w16_scale = pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16);
+        void* wp = nullptr;
+        API_TRY(e, e->ws.get("dbg#w16", w16.size() * 2, &wp));
+        API_HIP(e, hipMemcpy(wp, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+        a.w16 = wp;
+    }
     API_TRY(e, launch_conv(e->stream, a));
     hipEvent_t e0, e1;
     API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1));

@@ -107,8 +107,11 @@ struct ConvArgs {
     float* partial = nullptr;     // split-K slab (optional) and its capacity in floats
     size_t partial_capacity = 0;
     int dbg = 0;                  // ablation bits (debug bench only)
+    const void* w16 = nullptr;    // operand-split f16 weights (conv3.hip layout) or null -> exact fp32 kernels
+    float w16_scale = 1.f;        // power-of-two pre-scale of w16
 };
 Status launch_conv(hipStream_t s, const ConvArgs& a);
+float pack_weights_f16x3(const float* w_oihw, int cout, int cin, int ks, std::vector<uint16_t>& out);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // norm.hip

@@ -325,7 +325,7 @@ __global__ void conv_splitk_reduce_kernel(const float* partial, int ksplit, cons
 
 static int ilog2c(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-static const float* zero_page() {
+const float* conv_zero_page() {
     static std::map<int, float*> pages;        // one read-only zero page per device
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
@@ -381,7 +381,7 @@ Status launch_conv2(hipStream_t s, const ConvArgs& a) {
     k.w = a.w; k.bias = a.bias; k.out = a.out; k.res = a.res; k.res_mode = a.res_mode;
     k.B = a.B; k.Cin = a.Cin; k.Cout = a.Cout; k.CoutP = a.CoutP; k.H = a.H; k.W = a.W;
     k.partial = a.partial; k.ksplit = 1; k.chunks_per_split = 0; k.dbg = a.dbg;
-    k.zeros = zero_page();
+    k.zeros = conv_zero_page();
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv2: cannot allocate the zero page"};
     int tw = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : (a.W >= 8 ? 8 : 4));
     int th = 256 / tw;

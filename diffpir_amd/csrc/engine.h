@@ -26,7 +26,8 @@ struct Workspace {
     void release();
 };
 
-struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3; };
+struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3;
+               void* w16 = nullptr; float w16_scale = 1.f; };   // operand-split f16 copy (precision mode 1)
 struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 struct ResW {
     std::string name;
@@ -83,6 +84,7 @@ struct dpir_engine {
     std::map<std::pair<int, int>, dpir::ResizerTab> resizers;   // (in_len, sf)
     std::vector<void*> user_allocs;
     bool collect_taps = true;
+    int precision = 0;           // 0: exact fp32 MFMA kernels; 1: operand-split f16x3 MFMA (fp32-equivalent accuracy)
     struct GraphEntry { hipGraphExec_t exec = nullptr; };
     std::map<uint64_t, GraphEntry> graphs;       // captured restoration loops, keyed by descriptor content
     dpir::ProxState loop_prox;                   // spectra owned by dpir_run_loop

@@ -78,6 +78,15 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
     DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
     DPIR_TRY(upload(e, b, cout, &out->bias));
+    if (e->precision == 1) {
+        std::vector<uint16_t> w16;
+        out->w16_scale = pack_weights_f16x3(w, cout, cin, ks, w16);
+        void* p = nullptr;
+        if (hipMalloc(&p, w16.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for split weights failed"};
+        e->net.allocs.push_back(p);
+        DPIR_HIP(hipMemcpy(p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+        out->w16 = p;
+    }
     return Status{};
 }
 Status load_gn(dpir_engine* e, const WeightMap& wm, const std::string& p, int c, GnW* out) {
@@ -270,6 +279,7 @@ struct Fwd {
         a.w = cw.w; a.bias = cw.bias; a.out = out; a.res = res; a.res_mode = res_mode;
         a.B = B; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutP = cw.coutp; a.H = Ho; a.W = Wo; a.ks = cw.ks;
         a.partial = partial; a.partial_capacity = partial_cap;
+        a.w16 = cw.w16; a.w16_scale = cw.w16_scale;
         ProfScope ps(&e->prof, cw.ks == 3 ? PC_CONV3 : PC_CONV1);
         return launch_conv(s, a);
     }

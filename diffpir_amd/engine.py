@@ -116,6 +116,14 @@ class Engine:
         self._check(self.lib.dpir_sync(self.h))
 
     # ---- UNet
+    def set_precision(self, mode):
+        """'f32' (exact fp32 MFMA) or 'f16x3' (operand-split f16 MFMA, fp32-equivalent accuracy); before load_unet."""
+        m = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
+        self._check(self.lib.dpir_set_precision(self.h, m))
+        self.precision = "f16x3" if m else "f32"
+
+    precision = "f32"
+
     def load_unet(self, desc: "_lib.UNetDesc", state_dict: Dict[str, np.ndarray]):
         n = len(state_dict)
         arr = (_lib.Tensor * n)()

@@ -90,6 +90,12 @@ typedef struct dpir_tensor {
  * DPIR_ERR_INVALID naming the first missing / mis-shaped key. */
 int dpir_load_unet(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* weights, int n_weights);
 
+/* Arithmetic of the convolution / attention GEMMs, to be chosen BEFORE dpir_load_unet (weights are packed for it):
+ *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default;
+ *   1  operand-split f16 MFMA: x = hi + lo in f16, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation --
+ *      22-bit products, measured error <= the fp32 MFMA chain's, 5.3x its rate. */
+int dpir_set_precision(dpir_engine* e, int mode);
+
 /* Replaces UNetModel.forward (guided_diffusion/unet.py:634-663): x_dev [B,3,H,W], t_host [B] int64
  * timesteps (host), y_host [B] int64 labels or NULL -> out_dev [B,out_channels,H,W]. */
 int dpir_unet_forward(dpir_engine* e, const float* x_dev, const int64_t* t_host, const int64_t* y_host,

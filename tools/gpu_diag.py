@@ -10,6 +10,9 @@ from tests.gpu_common import make_model, rel_err
 
 def main():
     e = diffpir_amd.Engine(0)
+    prec = os.environ.get("DIFFPIR_PRECISION", "f32")
+    e.set_precision(prec)
+    print("precision", prec)
     for tag, hp, B, H, W in (("tiny", uo.tiny_hp(), 2, 32, 32), ("ffhq64", uo.ffhq_hp(), 1, 64, 64)):
         model, sd = make_model(e, hp)
         g = torch.Generator().manual_seed(3)
