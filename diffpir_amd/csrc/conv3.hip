@@ -177,14 +177,13 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3K p) {
         }
         const bool in_a = c0 < p.ca;                        // a chunk never straddles the concat boundary (checked on the host)
         const int cb0 = in_a ? c0 : c0 - p.ca;
+        const int cmax = (in_a ? p.ca : p.cb) - 1;
 #pragma unroll
         for (int q = 0; q < NT; ++q) {
             const float* base = (in_a ? tk_pa[q] : tk_pb[q]);
+            const int cfirst = cb0 + 8 * tk_kg[q];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                int cc = min(cb0 + 8 * tk_kg[q] + j, (in_a ? p.ca : p.cb) - 1);
-                vals[q][j] = base[(size_t)cc * tk_cs[q]];
-            }
+            for (int j = 0; j < 8; ++j) vals[q][j] = base[min(cfirst + j, cmax) * tk_cs[q]];   // 32-bit offsets (< 2^31 floats per tensor slice)
         }
     };
     auto store_acts = [&](int buf, int c0) {
@@ -240,31 +239,37 @@ __global__ __launch_bounds__(256, 2) void conv3_mfma_kernel(Conv3K p) {
             const half8* wl = wh + WPLANE / 8;
             const half8* xh = reinterpret_cast<const half8*>(lds_x + (size_t)(cur * 2) * XPLANE);
             const half8* xl = xh + XPLANE / 8;
-#pragma unroll
-            for (int tap = 0; tap < TAPS; ++tap) {
+            // operands of step s+1 (one (tap, k16-block) pair = 12 MFMAs) are read from LDS while step s computes
+            constexpr int NSTEP = TAPS * KB;
+            half8 ah[2][WCO], al[2][WCO], bh[2][WPX], bl[2][WPX];
+            auto load_step = [&](int st, int buf) {
+                const int tap = st / KB, kb = st % KB;
                 const int toff = (KS == 3) ? (tap / 3) * LW + (tap % 3) : 0;
 #pragma unroll
-                for (int kb = 0; kb < KB; ++kb) {
-                    half8 ah[WCO], al[WCO], bh[WPX], bl[WPX];
+                for (int i = 0; i < WCO; ++i) {
+                    int o = (tap * 2 * KB + kb * 2) * BCO + aoff + i * 32;
+                    ah[buf][i] = wh[o]; al[buf][i] = wl[o];
+                }
 #pragma unroll
-                    for (int i = 0; i < WCO; ++i) {
-                        int o = (tap * 2 * KB + kb * 2) * BCO + aoff + i * 32;
-                        ah[i] = wh[o]; al[i] = wl[o];
-                    }
+                for (int j = 0; j < WPX; ++j) {
+                    int o = kb * 2 * PMAX + boff[j] + toff;
+                    bh[buf][j] = xh[o]; bl[buf][j] = xl[o];
+                }
+            };
+            load_step(0, 0);
+#pragma unroll
+            for (int st = 0; st < NSTEP; ++st) {
+                if (st + 1 < NSTEP) load_step(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
 #pragma unroll
                     for (int j = 0; j < WPX; ++j) {
-                        int o = kb * 2 * PMAX + boff[j] + toff;
-                        bh[j] = xh[o]; bl[j] = xl[o];
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[st & 1][i], bh[st & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][i], bl[st & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[st & 1][i], bh[st & 1][j], acc[i][j], 0, 0, 0);
                     }
-#pragma unroll
-                    for (int i = 0; i < WCO; ++i)
-#pragma unroll
-                        for (int j = 0; j < WPX; ++j) {
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
-                        }
-                }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         if (more) store_acts(cur ^ 1, (chunk + 1) * KC);

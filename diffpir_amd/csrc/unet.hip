@@ -78,7 +78,7 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
     DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
     DPIR_TRY(upload(e, b, cout, &out->bias));
-    if (e->precision == 1) {
+    if (e->precision == 1 && ks == 3) {
         std::vector<uint16_t> w16;
         out->w16_scale = pack_weights_f16x3(w, cout, cin, ks, w16);
         void* p = nullptr;

@@ -6,8 +6,10 @@ from diffpir_amd import _lib, script_util
 from oracle import unet_oracle as uo
 
 
-def make_model(engine, hp: uo.UNetHP, seed=0):
+def make_model(engine, hp: uo.UNetHP, seed=0, precision=None):
     """Build the engine model through the reference-shaped factory and load the oracle's synthetic weights."""
+    if precision is not None:
+        engine.set_precision(precision)
     model = script_util.create_model(
         image_size=hp.image_size, num_channels=hp.model_channels, num_res_blocks=hp.num_res_blocks,
         channel_mult=",".join(str(c) for c in hp.channel_mult) if hp.channel_mult else "",

@@ -100,10 +100,14 @@ def test_u8_output_and_skip_dead_final_eval(engine, tiny, golden):
     np.testing.assert_array_equal(g, f.numpy())        # Q2: the last UNet evaluation never reaches the output
 
 
-def test_config_c1_full_size_psnr_parity(engine):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_config_c1_full_size_psnr_parity(precision):
     """BASELINE config 1: FFHQ topology, 256x256 box inpainting, 20 NFE, B=1 -- engine vs oracle on identical
     y / mask / weights / host-drawn noise: |dPSNR| <= 1e-3 dB (north-star tolerance)."""
+    import diffpir_amd
     from diffpir_amd import synth
+    engine = diffpir_amd.Engine(0)
+    engine.set_precision(precision)
     hp = uo.ffhq_hp()
     model, sd = make_model(engine, hp)
     case = synth.make_case("inpaint", B=1, H=256, W=256, seed=42)
@@ -115,7 +119,8 @@ def test_config_c1_full_size_psnr_parity(engine):
                      noise_fn=seeded_noise_fn_torch(42)).numpy()
     gt = case["gt"] * 2 - 1
     p_eng, p_ref = restore.psnr_batch(out * 2 - 1, gt), restore.psnr_batch(ref * 2 - 1, gt)
-    print(f"C1 PSNR engine {p_eng:.5f} dB, oracle {p_ref:.5f} dB, max|diff| {np.abs(out - ref).max():.3e}")
+    print(f"C1 [{precision}] PSNR engine {p_eng:.5f} dB, oracle {p_ref:.5f} dB, max|diff| {np.abs(out - ref).max():.3e}")
     assert abs(p_eng - p_ref) <= 1e-3
     # integer mask semantics: kept pixels follow the data term exactly as in the oracle
     assert np.abs(out - ref).max() < 5e-3
+    engine.close()

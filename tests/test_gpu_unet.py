@@ -80,6 +80,31 @@ def test_ffhq_topology_256_full_size(engine):
     assert engine.unet_flops(256, 256) == pytest.approx(387.934e9, rel=1e-5)
 
 
+@pytest.fixture()
+def engine_f16x3():
+    """A separate engine in operand-split f16x3 MFMA mode (precision is fixed before the weights are packed)."""
+    import diffpir_amd
+    e = diffpir_amd.Engine(0)
+    e.set_precision("f16x3")
+    yield e
+    e.close()
+
+
+def test_f16x3_mode_layers_match_oracle_like_fp32(engine_f16x3):
+    """Same per-layer tolerance as the exact-fp32 kernels: the split product keeps 22 mantissa bits and accumulates in fp32."""
+    _run_and_compare(engine_f16x3, uo.tiny_hp(), 2, 32, 32)
+    _run_and_compare(engine_f16x3, uo.tiny_hp(), 3, 64, 64)
+    _run_and_compare(engine_f16x3, uo.ffhq_hp(), 2, 64, 64)
+
+
+def test_f16x3_mode_full_size_and_fixture(engine_f16x3, golden):
+    out, ref = _run_and_compare(engine_f16x3, uo.ffhq_hp(), 1, 256, 256, check_taps=False)
+    assert rel_err(out, ref) < 1e-5
+    g = golden("unet_ffhq")
+    o = engine_f16x3.unet_forward(engine_f16x3.to_device(g["x"]), g["t"]).numpy()
+    assert rel_err(o, g["out"]) < 1e-5
+
+
 def test_missing_weight_is_reported(engine):
     import diffpir_amd
     from diffpir_amd import script_util
