@@ -707,11 +707,29 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         API_HIP(e, hipMemcpy(wp, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
         a.w16 = wp;
     }
-    API_TRY(e, launch_conv(e->stream, a));
+    Conv4Args a4;
+    bool use4 = (dbg & 128) != 0;
+    if (use4) {
+        if (!a.w16) return fail(e, invalid("debug bench: conv4 needs dbg bit 64 (split weights) as well"));
+        int C8 = 2 * ((Cin + 15) / 16);
+        size_t plane = (size_t)B * C8 * H * W * 16;
+        char* s16 = nullptr;
+        API_TRY(e, e->ws.getT("dbg#s16", 2 * plane, &s16));
+        if (!(dbg & 256)) API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, s16, s16 + plane));
+        a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = a.w16; a4.w16_scale = a.w16_scale; a4.bias = bias; a4.out = out;
+        a4.B = B; a4.Cin = Cin; a4.Cout = Cout; a4.H = H; a4.W = W; a4.partial = partial; a4.partial_capacity = a.partial_capacity;
+        a4.dbg = dbg & 31;
+    }
+    auto run_once = [&]() -> Status {
+        if (!use4) return launch_conv(e->stream, a);
+        if (!(dbg & 256)) DPIR_TRY(launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, const_cast<void*>(a4.xhi), const_cast<void*>(a4.xlo)));
+        return launch_conv4(e->stream, a4);
+    };
+    API_TRY(e, run_once());
     hipEvent_t e0, e1;
     API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1));
     API_HIP(e, hipEventRecord(e0, e->stream));
-    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv(e->stream, a));
+    for (int i = 0; i < iters; ++i) API_TRY(e, run_once());
     API_HIP(e, hipEventRecord(e1, e->stream));
     API_HIP(e, hipEventSynchronize(e1));
     float ms = 0; API_HIP(e, hipEventElapsedTime(&ms, e0, e1));

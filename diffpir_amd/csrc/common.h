@@ -116,6 +116,19 @@ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // norm.hip
 struct CatSrc { const float* a; int ca; const float* b; int cb; };
+
+// act.hip + conv4.hip: operand-split f16 path with a separate activation pre-pass
+// hi / lo: blocked [B][C8][H][W][8] f16 planes, C8 = 2*ceil(C/16); mode: 0 plain, 1 nearest-up source, 2 avg-pool source
+Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo);
+struct Conv4Args {
+    const void* xhi = nullptr; const void* xlo = nullptr;   // split activations (Cin channels, output resolution)
+    const void* w16 = nullptr; float w16_scale = 1.f;
+    const float* bias = nullptr; float* out = nullptr; const float* res = nullptr; int res_mode = 0;
+    int B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
+    float* partial = nullptr; size_t partial_capacity = 0; int dbg = 0;
+};
+bool conv4_supported(int H, int W);
+Status launch_conv4(hipStream_t s, const Conv4Args& a);
 // stats[n*32+g] = {mean, rstd} over the (virtual-concat) group
 Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, float2* stats);
 // prm[n*C+c] = {mean, rstd*gamma*(1+scale), beta*(1+scale)+shift, silu?1:0}; film = [B, film_stride] rows with

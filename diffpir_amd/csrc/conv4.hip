@@ -1,0 +1,311 @@
+// conv4: 3x3 implicit-GEMM convolution on the f16 matrix pipe with operand splitting (see conv3.hip for the
+// arithmetic and its measured accuracy), fed ONLY by LDS-DMA: the activation operand has already been normalised,
+// activated, resampled, concatenated and split into f16 hi/lo halves by act.hip, in the blocked layout
+// [n][C/8][H][W][8] whose 16-byte entries are exactly one lane's MFMA B-operand fragment.  The kernel contains no
+// staging arithmetic at all: per K chunk of 16 input channels a workgroup issues
+//     36 x 1 KiB weight pieces  + 2 x 21 x 1 KiB activation pieces (hi, lo)     (global_load_lds_dwordx4)
+// into the other half of a double buffer and runs 9 taps x 4 tiles x 3 = 108 MFMAs per wave out of the current one.
+// Tile: 64 output channels x 512 pixels (16 x 32 patch), 8 waves x (64 x 64): two waves per SIMD, weight traffic per
+// MFMA half of the 256-pixel tile's.  LDS: 2 x 36 KiB weights + 2 x 2 x 21 KiB activations = 156 KiB, one workgroup per CU.
+#include "common.h"
+
+namespace dpir {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct Conv4K {
+    const char* xhi; const char* xlo;      // blocked split activations [n][C8][H][W][16 B]
+    int C8;
+    const char* w16; const float* bias; float* out; const float* res; int res_mode;
+    int B, Cout, H, W;
+    int n_chunks_total;
+    int ltw, lth, ti;
+    int tiles_x, tiles_y, n_ptiles, n_co_blocks;
+    int chs;
+    int ksplit, chunks_per_split;
+    float* partial;
+    const float* zeros;
+    float out_scale;
+    int dbg;
+};
+
+#define GLDS4(src, dst) \
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
+                                     (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+__global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
+    constexpr int TAPS = 9, BCO = 64, WCO = 2, WPX = 2;
+    constexpr int PMAX = 648;                       // patch positions per k-half plane
+    constexpr int XPIECES = (2 * PMAX + 63) / 64;   // 21 DMA pieces of 64 entries per plane (hi or lo)
+    constexpr int XBYTES = XPIECES * 1024;          // bytes per plane buffer
+    constexpr int WBYTES = 2 * TAPS * 2 * BCO * 16; // hi + lo weight chunk: 36864
+    constexpr int WPIECES = WBYTES / 1024;          // 36
+    constexpr int NXT = (XPIECES + 7) / 8;          // activation pieces per wave (per plane)
+    constexpr int NWT = (WPIECES + 7) / 8;          // weight pieces per wave
+    extern __shared__ __attribute__((aligned(16))) char smem4[];
+    char* lds_w = smem4;                            // [2][WBYTES]
+    char* lds_x = smem4 + 2 * WBYTES;               // [2][hi|lo][XBYTES]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    int bid = blockIdx.x;
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
+    const int co_blk = bid % p.n_co_blocks;
+    const int ptile = bid / p.n_co_blocks;
+    const int co0 = co_blk * BCO;
+    const int TW = 1 << p.ltw, TH = 1 << p.lth, TI = p.ti;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int img_grp = ptile / tiles_per_img;
+    const int trem = ptile - img_grp * tiles_per_img;
+    const int ty0 = (trem / p.tiles_x) * TH;
+    const int tx0 = (trem % p.tiles_x) * TW;
+    const int n0 = img_grp * TI;
+    const int LW = TW + 2, LH = TH + 2;
+    const int HW = p.H * p.W;
+
+    // ---- per-lane DMA source offsets of this wave's activation pieces (chunk invariant, in 16-byte entries)
+    int x_off[NXT];      // entry offset of (n, kg, gy, gx) inside the blocked tensor for chunk 0; -1 = zero page
+#pragma unroll
+    for (int u = 0; u < NXT; ++u) {
+        int piece = wave + u * 8;
+        int f = piece * 64 + lane;
+        int kg = f / PMAX;
+        int e = f - kg * PMAX;
+        int ti = e / (LH * LW);
+        int rr = e - ti * (LH * LW);
+        int hy = rr / LW, hx = rr - hy * LW;
+        int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        int n = n0 + ti;
+        bool ok = piece < XPIECES && kg < 2 && e < p.chs && ti < TI && n < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        x_off[u] = ok ? ((n * p.C8 + kg) * HW + gy * p.W + gx) : -1;
+    }
+
+    // ---- per-lane MFMA operand offsets (16-byte entries)
+    int boff[WPX];
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        int pp = (wave * WPX + j) * 32 + l31;
+        int px = pp & (TW - 1);
+        int py = (pp >> p.ltw) & (TH - 1);
+        int ti = pp >> (p.ltw + p.lth);
+        if (ti >= TI) ti = 0;
+        boff[j] = ti * (LH * LW) + py * LW + px + half * PMAX;
+    }
+    const int aoff = half * BCO + l31;
+
+    floatx16 acc[WCO][WPX];
+#pragma unroll
+    for (int i = 0; i < WCO; ++i)
+#pragma unroll
+        for (int j = 0; j < WPX; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int ch_begin = split * p.chunks_per_split;
+    const int ch_end = min(p.n_chunks_total, ch_begin + p.chunks_per_split);
+
+    auto issue_dma = [&](int chunk, int buf) {
+        if (p.dbg & 4) return;
+        const char* wsrc = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * WBYTES + lane * 16;
+        char* wdst = lds_w + buf * WBYTES;
+#pragma unroll
+        for (int u = 0; u < NWT; ++u) {
+            int piece = wave + u * 8;
+            if (piece < WPIECES) GLDS4(wsrc + piece * 1024, wdst + piece * 1024);
+        }
+        const size_t coff = (size_t)chunk * 2 * HW;          // two C8 groups per chunk
+        char* xdst = lds_x + buf * 2 * XBYTES;
+#pragma unroll
+        for (int u = 0; u < NXT; ++u) {
+            int piece = wave + u * 8;
+            if (piece < XPIECES) {
+                const bool ok = x_off[u] >= 0;
+                const size_t ent = ok ? (size_t)x_off[u] + coff : 0;
+                const char* sh = ok ? p.xhi + ent * 16 : reinterpret_cast<const char*>(p.zeros);
+                const char* sl = ok ? p.xlo + ent * 16 : reinterpret_cast<const char*>(p.zeros);
+                GLDS4(sh, xdst + piece * 1024);
+                GLDS4(sl, xdst + XBYTES + piece * 1024);
+            }
+        }
+    };
+
+    issue_dma(ch_begin, 0);
+    int it = 0;
+    for (int chunk = ch_begin; chunk < ch_end; ++chunk, ++it) {
+        const int cur = it & 1;
+        __syncthreads();                    // every wave's DMAs of this chunk have landed (vmcnt(0) precedes the barrier)
+        if (chunk + 1 < ch_end) issue_dma(chunk + 1, cur ^ 1);
+
+        if (!(p.dbg & 1)) {
+            const half8* wh = reinterpret_cast<const half8*>(lds_w + cur * WBYTES);
+            const half8* wl = wh + WBYTES / 32;
+            const half8* xh = reinterpret_cast<const half8*>(lds_x + cur * 2 * XBYTES);
+            const half8* xl = xh + XBYTES / 16;
+            half8 ah[2][WCO], al[2][WCO], bh[2][WPX], bl[2][WPX];
+            auto load_step = [&](int tap, int buf) {
+                const int toff = (tap / 3) * LW + (tap % 3);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) {
+                    int o = tap * 2 * BCO + aoff + i * 32;
+                    ah[buf][i] = wh[o]; al[buf][i] = wl[o];
+                }
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) {
+                    int o = boff[j] + toff;
+                    bh[buf][j] = xh[o]; bl[buf][j] = xl[o];
+                }
+            };
+            load_step(0, 0);
+#pragma unroll
+            for (int tap = 0; tap < TAPS; ++tap) {
+                if (tap + 1 < TAPS) load_step(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j) {
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][i], bl[tap & 1][j], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+
+    // ---- epilogue: un-scale, bias + residual, 128-byte coalesced NCHW stores
+    const bool full_co = co0 + BCO <= p.Cout;
+#pragma unroll
+    for (int j = 0; j < WPX; ++j) {
+        int pp = (wave * WPX + j) * 32 + l31;
+        int px = pp & (TW - 1);
+        int py = (pp >> p.ltw) & (TH - 1);
+        int ti = pp >> (p.ltw + p.lth);
+        int n = n0 + ti, y = ty0 + py, x = tx0 + px;
+        bool pok = ti < TI && n < p.B && y < p.H && x < p.W;
+        if (p.dbg & 16) {
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (acc[i][j][r] == 1.2345e33f) p.out[0] = 1.f;
+            continue;
+        }
+        if (!pok) continue;
+        const size_t pix = (size_t)y * p.W + x;
+        if (p.ksplit > 1) {
+            float* pb = p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) + (size_t)n * p.Cout * HW + pix;
+#pragma unroll
+            for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (full_co || co < p.Cout) pb[(size_t)co * HW] = acc[i][j][r] * p.out_scale;
+                }
+            continue;
+        }
+        float* ob = p.out + (size_t)n * p.Cout * HW + pix;
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (full_co || co < p.Cout) {
+                    float v = acc[i][j][r] * p.out_scale + p.bias[co];
+                    if (p.res) {
+                        float rv;
+                        if (p.res_mode == 0) {
+                            rv = p.res[((size_t)n * p.Cout + co) * HW + pix];
+                        } else if (p.res_mode == 1) {
+                            int Hr = p.H >> 1, Wr = p.W >> 1;
+                            rv = p.res[((size_t)n * p.Cout + co) * (Hr * Wr) + (y >> 1) * Wr + (x >> 1)];
+                        } else {
+                            int Wr = p.W * 2;
+                            const float* rp = p.res + ((size_t)n * p.Cout + co) * (4 * HW) + (2 * y) * Wr + 2 * x;
+                            rv = ((rp[0] + rp[1]) + (rp[Wr] + rp[Wr + 1])) * 0.25f;
+                        }
+                        v = rv + v;
+                    }
+                    ob[(size_t)co * HW] = v;
+                }
+            }
+    }
+}
+
+__global__ void conv_splitk_reduce_kernel(const float* partial, int ksplit, const float* bias, const float* res, int res_mode,
+                                          float* out, int Cout, int H, int W, size_t total);
+const float* conv_zero_page();
+
+static int ilog2e(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
+
+// geometry shared with the executor: does conv4 tile this output shape?
+bool conv4_supported(int H, int W) {
+    if (W < 16) return false;
+    int tw = W >= 32 ? 32 : 16;
+    int th = 512 / tw;
+    int hp2 = 1 << ilog2e(H);
+    if (th > hp2) th = hp2;
+    int ti = 512 / (tw * th);
+    if (ti > 8) return false;
+    return ti * (th + 2) * (tw + 2) <= 648;
+}
+
+Status launch_conv4(hipStream_t s, const Conv4Args& a) {
+    if (!conv4_supported(a.H, a.W)) return Status{DPIR_ERR_UNSUPPORTED, "conv4: shape not tiled"};
+    Conv4K k;
+    k.xhi = reinterpret_cast<const char*>(a.xhi); k.xlo = reinterpret_cast<const char*>(a.xlo); k.C8 = (a.Cin + 7) / 8;
+    k.w16 = reinterpret_cast<const char*>(a.w16); k.bias = a.bias; k.out = a.out; k.res = a.res; k.res_mode = a.res_mode;
+    k.B = a.B; k.Cout = a.Cout; k.H = a.H; k.W = a.W;
+    k.n_chunks_total = (a.Cin + 15) / 16;
+    k.C8 = 2 * k.n_chunks_total;          // act.hip pads the blocked tensor to whole 16-channel chunks
+    k.partial = a.partial; k.ksplit = 1; k.chunks_per_split = 0; k.dbg = a.dbg;
+    k.out_scale = 1.0f / a.w16_scale;
+    k.zeros = conv_zero_page();
+    if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv4: cannot allocate the zero page"};
+    int tw = a.W >= 32 ? 32 : 16;
+    int th = 512 / tw;
+    int hp2 = 1 << ilog2e(a.H);
+    if (th > hp2) th = hp2;
+    int ti = 512 / (tw * th);
+    k.ti = ti; k.ltw = ilog2e(tw); k.lth = ilog2e(th);
+    k.tiles_x = (a.W + tw - 1) / tw;
+    k.tiles_y = (a.H + th - 1) / th;
+    k.n_ptiles = k.tiles_x * k.tiles_y * ((a.B + ti - 1) / ti);
+    k.n_co_blocks = (a.Cout + 63) / 64;
+    k.chs = ti * (th + 2) * (tw + 2);
+    constexpr size_t LDS = 2 * 36864 + 2 * 2 * 21 * 1024;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv4_mfma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+    }
+    const int chunks = k.n_chunks_total;
+    const int blocks = k.n_ptiles * k.n_co_blocks;
+    int S = 1;
+    if (k.partial && blocks < 192) {
+        S = (256 + blocks - 1) / blocks;
+        if (S > chunks / 2) S = chunks / 2;
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+        if ((size_t)S * k.B * k.Cout * k.H * k.W > a.partial_capacity) S = 1;
+    }
+    k.ksplit = S;
+    k.chunks_per_split = (chunks + S - 1) / S;
+    if (S == 1) k.partial = nullptr;
+    hipLaunchKernelGGL(conv4_mfma_kernel, dim3((unsigned)(blocks * S)), dim3(512), LDS, s, k);
+    if (S > 1) {
+        size_t total = (size_t)k.B * k.Cout * k.H * k.W;
+        hipLaunchKernelGGL(conv_splitk_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, k.partial, S, k.bias,
+                           k.res, k.res_mode, k.out, k.Cout, k.H, k.W, total);
+    }
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+}  // namespace dpir

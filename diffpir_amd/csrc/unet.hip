@@ -273,6 +273,27 @@ struct Fwd {
     size_t partial_cap;
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
+        if (cw.w16 && cw.ks == 3 && conv4_supported(Ho, Wo)) {
+            // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split), then a
+            // convolution that is pure LDS-DMA + MFMA
+            int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
+            if (eh != in.H || ew != in.W) return invalid("conv: source resolution does not match mode");
+            const int C = in.C(), C8 = 2 * ((C + 15) / 16);
+            const size_t plane = (size_t)B * C8 * Ho * Wo * 16;
+            char* s16 = nullptr;
+            DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
+            {
+                ProfScope ps(&e->prof, PC_ELEM);
+                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane));
+            }
+            Conv4Args a4;
+            a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = cw.w16; a4.w16_scale = cw.w16_scale;
+            a4.bias = cw.bias; a4.out = out; a4.res = res; a4.res_mode = res_mode;
+            a4.B = B; a4.Cin = cw.cin; a4.Cout = cw.cout; a4.H = Ho; a4.W = Wo;
+            a4.partial = partial; a4.partial_capacity = partial_cap;
+            ProfScope ps(&e->prof, PC_CONV3);
+            return launch_conv4(s, a4);
+        }
         ConvArgs a;
         a.src.a = in.a; a.src.ca = in.ca; a.src.b = in.b; a.src.cb = in.cb; a.src.Hs = in.H; a.src.Ws = in.W;
         a.src.mode = mode; a.src.prm = prm;
