@@ -701,14 +701,20 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         std::vector<float> hw((size_t)Cout * Cin * taps);
         for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
         std::vector<uint16_t> w16;
-        a.w16_scale = pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16);
+        a.w16_scale = (ks == 1 && (dbg & 128)) ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16) : pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16);
         void* wp = nullptr;
         API_TRY(e, e->ws.get("dbg#w16", w16.size() * 2, &wp));
         API_HIP(e, hipMemcpy(wp, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
         a.w16 = wp;
     }
     Conv4Args a4;
-    bool use4 = (dbg & 128) != 0;
+    Conv5Args a5;
+    const bool use5 = (dbg & 128) != 0 && ks == 1;
+    if (use5) {
+        a5.src = CatSrc{x, Cin, nullptr, 0}; a5.prm = a.src.prm; a5.w16 = a.w16; a5.w16_scale = a.w16_scale; a5.bias = bias; a5.out = out;
+        a5.B = B; a5.Cout = Cout; a5.H = H; a5.W = W;
+    }
+    bool use4 = (dbg & 128) != 0 && ks == 3;
     if (use4) {
         if (!a.w16) return fail(e, invalid("debug bench: conv4 needs dbg bit 64 (split weights) as well"));
         int C8 = 2 * ((Cin + 15) / 16);
@@ -718,9 +724,10 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         if (!(dbg & 256)) API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, s16, s16 + plane));
         a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = a.w16; a4.w16_scale = a.w16_scale; a4.bias = bias; a4.out = out;
         a4.B = B; a4.Cin = Cin; a4.Cout = Cout; a4.H = H; a4.W = W; a4.partial = partial; a4.partial_capacity = a.partial_capacity;
-        a4.dbg = dbg & 31;
+        a4.dbg = (dbg & 31) | (dbg & 512);
     }
     auto run_once = [&]() -> Status {
+        if (use5) return launch_conv5(e->stream, a5);
         if (!use4) return launch_conv(e->stream, a);
         if (!(dbg & 256)) DPIR_TRY(launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, const_cast<void*>(a4.xhi), const_cast<void*>(a4.xlo)));
         return launch_conv4(e->stream, a4);

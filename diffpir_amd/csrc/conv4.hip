@@ -110,39 +110,42 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     const int ch_begin = split * p.chunks_per_split;
     const int ch_end = min(p.n_chunks_total, ch_begin + p.chunks_per_split);
 
-    auto issue_dma = [&](int chunk, int buf) {
+    // One DMA "slot" = one 1 KiB piece of this wave's share of a chunk: slots [0, NWT) are weight pieces, then (hi, lo)
+    // pairs of activation pieces.  The prologue issues all slots at once; in steady state they are spread over the first
+    // taps of the previous chunk (two per tap), so the vector-memory queue never fills and stalls the MFMA issue.
+    constexpr int NSLOT = NWT + 2 * NXT;
+    auto issue_slot = [&](int chunk, int buf, int slot) {
         if (p.dbg & 4) return;
-        const char* wsrc = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * WBYTES + lane * 16;
-        char* wdst = lds_w + buf * WBYTES;
-#pragma unroll
-        for (int u = 0; u < NWT; ++u) {
-            int piece = wave + u * 8;
-            if (piece < WPIECES) GLDS4(wsrc + piece * 1024, wdst + piece * 1024);
-        }
-        const size_t coff = (size_t)chunk * 2 * HW;          // two C8 groups per chunk
-        char* xdst = lds_x + buf * 2 * XBYTES;
-#pragma unroll
-        for (int u = 0; u < NXT; ++u) {
+        if (slot < NWT) {
+            int piece = wave + slot * 8;
+            const char* wsrc = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * WBYTES + lane * 16;
+            if (piece < WPIECES) GLDS4(wsrc + piece * 1024, lds_w + buf * WBYTES + piece * 1024);
+        } else {
+            const int u = (slot - NWT) >> 1, plane = (slot - NWT) & 1;
             int piece = wave + u * 8;
             if (piece < XPIECES) {
                 const bool ok = x_off[u] >= 0;
-                const size_t ent = ok ? (size_t)x_off[u] + coff : 0;
-                const char* sh = ok ? p.xhi + ent * 16 : reinterpret_cast<const char*>(p.zeros);
-                const char* sl = ok ? p.xlo + ent * 16 : reinterpret_cast<const char*>(p.zeros);
-                GLDS4(sh, xdst + piece * 1024);
-                GLDS4(sl, xdst + XBYTES + piece * 1024);
+                const size_t ent = ok ? (size_t)x_off[u] + (size_t)chunk * 2 * HW : 0;      // two C8 groups per chunk
+                const char* base = plane ? p.xlo : p.xhi;
+                const char* src = ok ? base + ent * 16 : reinterpret_cast<const char*>(p.zeros);
+                GLDS4(src, lds_x + buf * 2 * XBYTES + plane * XBYTES + piece * 1024);
             }
         }
     };
 
-    issue_dma(ch_begin, 0);
+#pragma unroll
+    for (int sl = 0; sl < NSLOT; ++sl) issue_slot(ch_begin, 0, sl);
     int it = 0;
     for (int chunk = ch_begin; chunk < ch_end; ++chunk, ++it) {
         const int cur = it & 1;
         __syncthreads();                    // every wave's DMAs of this chunk have landed (vmcnt(0) precedes the barrier)
-        if (chunk + 1 < ch_end) issue_dma(chunk + 1, cur ^ 1);
+        const bool more = chunk + 1 < ch_end;
 
-        if (!(p.dbg & 1)) {
+        if (p.dbg & 1) {
+            if (more)
+#pragma unroll
+                for (int sl = 0; sl < NSLOT; ++sl) issue_slot(chunk + 1, cur ^ 1, sl);
+        } else {
             const half8* wh = reinterpret_cast<const half8*>(lds_w + cur * WBYTES);
             const half8* wl = wh + WBYTES / 32;
             const half8* xh = reinterpret_cast<const half8*>(lds_x + cur * 2 * XBYTES);
@@ -164,22 +167,93 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
             load_step(0, 0);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
-                if (tap + 1 < TAPS) load_step(tap + 1, (tap + 1) & 1);
+                if (more) {
+                    if (2 * tap < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap);
+                    if (2 * tap + 1 < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap + 1);
+                }
+                if (tap + 1 < TAPS && !((p.dbg & 512) && it > 0)) load_step(tap + 1, (tap + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
+                // the three partial products of one accumulator are issued four MFMAs apart (no back-to-back dependency);
+                // small terms first, as in conv3
 #pragma unroll
                 for (int i = 0; i < WCO; ++i)
 #pragma unroll
-                    for (int j = 0; j < WPX; ++j) {
+                    for (int j = 0; j < WPX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][i], bl[tap & 1][j], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < WCO; ++i)
+#pragma unroll
+                    for (int j = 0; j < WPX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
-                    }
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
 
-    // ---- epilogue: un-scale, bias + residual, 128-byte coalesced NCHW stores
+    // ---- epilogue.  Vector path (W % 4 == 0): each wave transposes its 64co x 64px accumulators through its own 17 KiB
+    // LDS slab so that every lane owns 4 consecutive pixels of one channel: float4 residual loads and float4 NCHW stores
+    // (4 channel rows x 256 B per instruction) instead of 64 scalar stores per lane.
+    if ((p.W & 3) == 0 && !(p.dbg & 16)) {
+        constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
+        __syncthreads();                                         // operand buffers are dead from here on
+        float* tr = reinterpret_cast<float*>(smem4) + wave * (64 * TS);
+#pragma unroll
+        for (int i = 0; i < WCO; ++i)
+#pragma unroll
+            for (int j = 0; j < WPX; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    tr[(i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TS + j * 32 + l31] = acc[i][j][r] * p.out_scale;
+        __syncthreads();
+        const int q4 = lane & 15, rsub = lane >> 4;
+        const int pp = wave * 64 + q4 * 4;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> p.ltw) & (TH - 1);
+        const int ti = pp >> (p.ltw + p.lth);
+        const int n = n0 + ti, y = ty0 + py, x = tx0 + px;
+        if (!(ti < TI && n < p.B && y < p.H && x < p.W)) return;
+        const size_t pix = (size_t)y * p.W + x;
+        float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int co_l = it * 4 + rsub;
+            const int co = co0 + co_l;
+            if (co >= p.Cout) continue;
+            float4 v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
+            const size_t plane = (size_t)n * p.Cout + co;
+            if (p.ksplit == 1) {
+                const float bv = p.bias[co];
+                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                if (p.res) {
+                    if (p.res_mode == 0) {
+                        float4 rv = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
+                        v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+                    } else if (p.res_mode == 1) {
+                        int Hr = p.H >> 1, Wr = p.W >> 1;
+                        float2 rv = *reinterpret_cast<const float2*>(p.res + plane * (Hr * Wr) + (y >> 1) * Wr + (x >> 1));
+                        v.x = rv.x + v.x; v.y = rv.x + v.y; v.z = rv.y + v.z; v.w = rv.y + v.w;
+                    } else {
+                        int Wr = p.W * 2;
+                        const float* rp = p.res + plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
+                        float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
+                        float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
+                        v.x = ((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f + v.x;
+                        v.y = ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f + v.y;
+                        v.z = ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f + v.z;
+                        v.w = ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f + v.w;
+                    }
+                }
+            }
+            *reinterpret_cast<float4*>(dst + plane * HW + pix) = v;
+        }
+        return;
+    }
+    // scalar path (odd widths, and the "no epilogue" ablation)
     const bool full_co = co0 + BCO <= p.Cout;
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {

@@ -17,28 +17,38 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-// one block per (image, group); the group may straddle the two tensors of a virtual concat
-__global__ __launch_bounds__(256) void gn_stats_kernel(CatSrc src, int HW, float2* stats) {
+// Pass 1: one workgroup per (image, channel) plane -> fp64 {sum, sum of squares}; pass 2 (gn_prm_kernel) folds the
+// channels of a group in a fixed order.  B*C workgroups keep every CU busy even at batch 1 (B*32 group-blocks did not).
+__global__ __launch_bounds__(256) void gn_stats_kernel(CatSrc src, int HW, double2* part) {
     const int C = src.ca + src.cb;
-    const int cg = C / 32;
-    const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
+    const int n = blockIdx.x / C, c = blockIdx.x - n * C;
+    const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HW
+                                    : src.b + ((size_t)n * src.cb + (c - src.ca)) * HW;
     double s = 0.0, ss = 0.0;
-    for (int cc = 0; cc < cg; ++cc) {
-        int c = g * cg + cc;
-        const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HW
-                                        : src.b + ((size_t)n * src.cb + (c - src.ca)) * HW;
-        if ((HW & 3) == 0) {
-            const float4* p4 = reinterpret_cast<const float4*>(plane);
-            for (int i = threadIdx.x; i < (HW >> 2); i += 256) {
-                float4 v = p4[i];
-                s += (double)v.x + (double)v.y + (double)v.z + (double)v.w;
-                ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
-            }
-        } else {
-            for (int i = threadIdx.x; i < HW; i += 256) {
-                float v = plane[i];
-                s += v; ss += (double)v * v;
-            }
+    if ((HW & 3) == 0) {
+        const float4* p4 = reinterpret_cast<const float4*>(plane);
+        const int n4 = HW >> 2;
+        int i = threadIdx.x;
+        for (; i + 768 < n4; i += 1024) {
+            float4 v0 = p4[i], v1 = p4[i + 256], v2 = p4[i + 512], v3 = p4[i + 768];
+            s += ((double)v0.x + (double)v0.y) + ((double)v0.z + (double)v0.w);
+            ss += ((double)v0.x * v0.x + (double)v0.y * v0.y) + ((double)v0.z * v0.z + (double)v0.w * v0.w);
+            s += ((double)v1.x + (double)v1.y) + ((double)v1.z + (double)v1.w);
+            ss += ((double)v1.x * v1.x + (double)v1.y * v1.y) + ((double)v1.z * v1.z + (double)v1.w * v1.w);
+            s += ((double)v2.x + (double)v2.y) + ((double)v2.z + (double)v2.w);
+            ss += ((double)v2.x * v2.x + (double)v2.y * v2.y) + ((double)v2.z * v2.z + (double)v2.w * v2.w);
+            s += ((double)v3.x + (double)v3.y) + ((double)v3.z + (double)v3.w);
+            ss += ((double)v3.x * v3.x + (double)v3.y * v3.y) + ((double)v3.z * v3.z + (double)v3.w * v3.w);
+        }
+        for (; i < n4; i += 256) {
+            float4 v = p4[i];
+            s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+            ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+        }
+    } else {
+        for (int i = threadIdx.x; i < HW; i += 256) {
+            float v = plane[i];
+            s += v; ss += (double)v * v;
         }
     }
     __shared__ double red[2][4];
@@ -46,31 +56,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(CatSrc src, int HW, float
     int w = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) { red[0][w] = s; red[1][w] = ss; }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double S = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-        double SS = red[1][0] + red[1][1] + red[1][2] + red[1][3];
-        double cnt = (double)cg * HW;
-        double mean = S / cnt;
-        double var = SS / cnt - mean * mean;
-        if (var < 0) var = 0;
-        stats[blockIdx.x] = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
-    }
+    if (threadIdx.x == 0)
+        part[blockIdx.x] = make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
 }
 
-Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, float2* stats) {
+Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part) {
     int C = src.ca + src.cb;
     if (C % 32) return invalid("GroupNorm32 needs channels % 32 == 0");
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * 32), dim3(256), 0, s, src, HW, stats);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(B * C), dim3(256), 0, s, src, HW, part);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
-__global__ void gn_prm_kernel(const float2* stats, const float* gamma, const float* beta, const float* film,
+__global__ void gn_prm_kernel(const double2* part, int HW, const float* gamma, const float* beta, const float* film,
                               int film_stride, int film_off, int B, int C, float act, float4* prm) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= B * C) return;
     int n = i / C, c = i - n * C;
-    float2 st = stats[n * 32 + c / (C / 32)];
+    const int cg = C / 32;
+    const double2* pg = part + (size_t)n * C + (c / cg) * cg;
+    double S = 0.0, SS = 0.0;
+    for (int k = 0; k < cg; ++k) { S += pg[k].x; SS += pg[k].y; }
+    double cnt = (double)cg * HW;
+    double mean = S / cnt;
+    double var = SS / cnt - mean * mean;
+    if (var < 0) var = 0;
+    float2 st = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
     float a = st.y * gamma[c];
     float b = beta[c];
     if (film) {   // h = GN(h) * (1 + scale) + shift   (unet.py:250-251)
@@ -82,10 +93,10 @@ __global__ void gn_prm_kernel(const float2* stats, const float* gamma, const flo
     prm[i] = make_float4(st.x, a, b, act);
 }
 
-Status launch_gn_prm(hipStream_t s, const float2* stats, const float* gamma, const float* beta,
+Status launch_gn_prm(hipStream_t s, const double2* part, int HW, const float* gamma, const float* beta,
                      const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm) {
     int n = B * C;
-    hipLaunchKernelGGL(gn_prm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, stats, gamma, beta, film, film_stride,
+    hipLaunchKernelGGL(gn_prm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, HW, gamma, beta, film, film_stride,
                        film_off, B, C, silu ? 1.0f : 0.0f, prm);
     DPIR_HIP(hipGetLastError());
     return Status{};

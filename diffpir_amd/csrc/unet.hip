@@ -78,9 +78,9 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
     DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
     DPIR_TRY(upload(e, b, cout, &out->bias));
-    if (e->precision == 1 && ks == 3) {
+    if (e->precision == 1 && (ks == 3 || ks == 1)) {
         std::vector<uint16_t> w16;
-        out->w16_scale = pack_weights_f16x3(w, cout, cin, ks, w16);
+        out->w16_scale = ks == 3 ? pack_weights_f16x3(w, cout, cin, ks, w16) : pack_weights_f16x3_1x1(w, cout, cin, w16);
         void* p = nullptr;
         if (hipMalloc(&p, w16.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for split weights failed"};
         e->net.allocs.push_back(p);
@@ -294,6 +294,13 @@ struct Fwd {
             ProfScope ps(&e->prof, PC_CONV3);
             return launch_conv4(s, a4);
         }
+        if (cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo)) {
+            Conv5Args a5;
+            a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
+            a5.bias = cw.bias; a5.out = out; a5.res = res; a5.B = B; a5.Cout = cw.cout; a5.H = Ho; a5.W = Wo;
+            ProfScope ps(&e->prof, PC_CONV1);
+            return launch_conv5(s, a5);
+        }
         ConvArgs a;
         a.src.a = in.a; a.src.ca = in.ca; a.src.b = in.b; a.src.cb = in.cb; a.src.Hs = in.H; a.src.Ws = in.W;
         a.src.mode = mode; a.src.prm = prm;
@@ -305,15 +312,15 @@ struct Fwd {
         return launch_conv(s, a);
     }
     Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out) {
-        float2* stats = nullptr; float4* prm = nullptr;
-        DPIR_TRY(ws.getT(tag + "#stats", (size_t)B * 32, &stats));
+        double2* stats = nullptr; float4* prm = nullptr;
+        DPIR_TRY(ws.getT(tag + "#stats", (size_t)B * g.c, &stats));
         DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * g.c, &prm));
         {
             ProfScope ps(&e->prof, PC_GN);
             DPIR_TRY(launch_gn_stats(s, CatSrc{in.a, in.ca, in.b, in.cb}, B, in.H * in.W, stats));
         }
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_gn_prm(s, stats, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
+        DPIR_TRY(launch_gn_prm(s, stats, in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
         *prm_out = prm;
         return Status{};
     }
