@@ -33,6 +33,9 @@ if ROOT not in sys.path:
 
 PEAK_FP32_MFMA_TFLOPS = 157.3   # /opt/skills/guides/MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 PEAK_F16X3_TFLOPS = 2500.0 / 3   # dense f16 MFMA peak / 3 MFMAs per fp32-equivalent product
+# HBM-side bytes per launch of the roofline kernel, from the committed PMC passes (bench.py cannot run rocprofv3 on itself):
+# f16x3: conv4_mfma_kernel (2 x 314570.6 + 155571.1) KB; f32: conv2/conv kernels (2 x 283 + 132) MB (profiles/r01/README.md)
+PMC_TRAFFIC_BYTES_PER_LAUNCH = {"f16x3": int((2 * 314570.6 + 155571.1) * 1024), "f32": int((2 * 283 + 132) * 1e6)}
 
 
 def parse():
@@ -47,7 +50,9 @@ def parse():
     ap.add_argument("--model", default="ffhq", choices=["ffhq", "imagenet256"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", default="f32", choices=["f32", "f16x3"], help="arithmetic of the conv GEMMs for the headline value")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="arithmetic of the conv GEMMs for the headline value: f16x3 = fp32 operands split into f16 hi+lo, three f16 MFMAs "
+                         "per product, fp32 accumulate (fp32-equivalent results, see DESIGN.md); f32 = v_mfma_f32_32x32x2_f32")
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement in the other precision mode")
     ap.add_argument("--cpu-nfe", type=int, default=6, help="NFE steps of the CPU oracle sample (B=1)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle sample (all 256 host\n                    threads oversubscribe MKL-DNN at B=1: 79 s/NFE measured vs ~1-2 s/NFE at 32)")
@@ -151,10 +156,13 @@ def main():
         achieved = fl / (ms * 1e-3) / 1e12
         peak = PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16X3_TFLOPS
         kern = ("conv2_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32, exact fp32)" if args.precision == "f32"
-                else "conv3_mfma_kernel<3x3> (3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product)")
+                else "conv4_mfma_kernel<3x3> (3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split4_kernel)")
         roofline = {"bound": "mfma", "kernel": kern,
                     "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "frac": round(achieved / peak, 4), "traffic": PMC_TRAFFIC_BYTES_PER_LAUNCH.get(args.precision) if (B, H, args.model) == (16, 256, "ffhq") else None,
+                    "traffic_source": "profiles/r01/pmc_{FETCH,WRITE}_SIZE_prof_forward_*.txt: separate rocprofv3 --pmc passes over tools/prof_forward.py "
+                                      "(same model, batch and kernels), FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, KB -> bytes, "
+                                      "average over this kernel's launches of a forward",
                     "launches": int(cnt), "avg_launch_ms": round(ms / max(cnt, 1), 4),
                     "flops_per_launch_avg": fl / max(cnt, 1),
                     "unet_forward_ms": round(prof["unet_forward"][0] / n_pass, 3),
@@ -218,7 +226,7 @@ def main():
         line = {"metric": "restored images/sec @100 NFE, 256x256", "value": round(value, 4), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
-                "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 via operand-split f16x3 MFMA (fp32 accumulate)",
+                "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (GEMMs as 3 x f16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; exact-fp32-MFMA mode in alt_precision)",
                 "data": "synthetic",
                 "config": {"workload": f"configs[1]: {args.model} topology {H}x{H} {args.task} "
                                        f"({'61x61 Gaussian PSF' if args.task == 'deblur' else args.task}), {args.nfe} NFE, "

@@ -66,13 +66,13 @@ __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4
 __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float4* prm, int C, int C8, int HW, _Float16* hi, _Float16* lo) {
     const int p4 = blockIdx.x * 256 + threadIdx.x;          // group of 4 pixels
     const int n = blockIdx.y / C8, c8 = blockIdx.y - n * C8;
-    if (p4 * 4 >= HW) return;
+    const bool live = p4 * 4 < HW;
     float4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c < C) {
+        if (c < C && live) {
             const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HW : src.b + ((size_t)n * src.cb + (c - src.ca)) * HW;
             v[j] = *reinterpret_cast<const float4*>(plane + (size_t)p4 * 4);
         }
@@ -89,7 +89,11 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
             }
         }
     }
-    const size_t o = (((size_t)n * C8 + c8) * HW + (size_t)p4 * 4) * 8;
+    // The thread's 4 pixels are 4 consecutive 16-byte entries per plane; written directly that is a 64-byte lane stride
+    // (quarter-dense store instructions).  Transpose through LDS ([q][thread] -> entry order) so that every store
+    // instruction writes 1 KiB of consecutive entries.
+    constexpr int PS = 256 + 4;                                 // plane stride in entries: conflict-free reads
+    __shared__ half8 sh_hi[4 * PS], sh_lo[4 * PS];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         half8 h8, l8;
@@ -101,8 +105,22 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
             h8[j] = hh;
             l8[j] = (_Float16)(x - (float)hh);
         }
-        *reinterpret_cast<half8*>(hi + o + q * 8) = h8;
-        *reinterpret_cast<half8*>(lo + o + q * 8) = l8;
+        sh_hi[q * PS + threadIdx.x] = h8;
+        sh_lo[q * PS + threadIdx.x] = l8;
+    }
+    __syncthreads();
+    const size_t o = ((size_t)n * C8 + c8) * HW + (size_t)blockIdx.x * 1024;      // first entry of this workgroup
+    const int rem = HW - blockIdx.x * 1024;                                        // valid entries (multiple of 4)
+    half8* gh = reinterpret_cast<half8*>(hi) + o;
+    half8* gl = reinterpret_cast<half8*>(lo) + o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int e = threadIdx.x + 256 * k;                     // entry = 4 * thread' + q'
+        if (e < rem) {
+            const int sl = (e & 3) * PS + (e >> 2);
+            gh[e] = sh_hi[sl];
+            gl[e] = sh_lo[sl];
+        }
     }
 }
 

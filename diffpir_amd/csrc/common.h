@@ -126,9 +126,11 @@ struct Conv4Args {
     const float* bias = nullptr; float* out = nullptr; const float* res = nullptr; int res_mode = 0;
     int B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
     float* partial = nullptr; size_t partial_capacity = 0; int dbg = 0;
+    float2* stat = nullptr;   // optional [B][Cout][conv4_stat_slots(H, W)] GroupNorm partial sums of the output
 };
 bool conv4_supported(int H, int W);
-Status launch_conv4(hipStream_t s, const Conv4Args& a);
+int conv4_stat_slots(int H, int W);
+Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written = nullptr);
 // conv5.hip: 1x1 convolution, f16x3 with the operand split done in-kernel from the fp32 NCHW (virtual concat) input
 struct Conv5Args {
     CatSrc src; const float4* prm = nullptr;
@@ -141,9 +143,12 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a);
 float pack_weights_f16x3_1x1(const float* w_oi, int cout, int cin, std::vector<uint16_t>& out);
 // part[n*C+c] = fp64 {sum, sum of squares} of one channel plane of the (virtual-concat) input
 Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part);
+// statistics of one tensor of a virtual concat: conv4 epilogue slots [B][c][nslots] (float2) or, when slots == null,
+// gn_stats partials [B][c] (double2)
+struct GnStatSrc { const float2* slots = nullptr; int nslots = 0; const double2* part = nullptr; int c = 0; };
 // prm[n*C+c] = {mean, rstd*gamma*(1+scale), beta*(1+scale)+shift, silu?1:0}; film = [B, film_stride] rows with
 // scale at film[n*film_stride + film_off + c], shift at +C; film == null -> plain GroupNorm
-Status launch_gn_prm(hipStream_t s, const double2* part, int HW, const float* gamma, const float* beta,
+Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
                      const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm);
 // time embedding MLP: t_dev [B] int32 -> semb [B, ted] = silu(time_embed(timestep_embedding(t)) + label_emb[y])
 Status launch_time_embed(hipStream_t s, const int* t_dev, const int* y_dev, const float* freqs, const float* w0, const float* b0,

@@ -28,11 +28,17 @@ struct Conv4K {
     const float* zeros;
     float out_scale;
     int dbg;
+    float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
 };
 
 #define GLDS4(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
 
 __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     constexpr int TAPS = 9, BCO = 64, WCO = 2, WPX = 2;
@@ -53,7 +59,10 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2); renumber them so that
+    // one XCD owns a contiguous range - the co-blocks of a pixel tile and neighbouring tiles then share an L2
     int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int split = bid % p.ksplit;
     bid /= p.ksplit;
     const int co_blk = bid % p.n_co_blocks;
@@ -117,10 +126,12 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     auto issue_slot = [&](int chunk, int buf, int slot) {
         if (p.dbg & 4) return;
         if (slot < NWT) {
+            if (p.dbg & 1024) return;
             int piece = wave + slot * 8;
             const char* wsrc = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * WBYTES + lane * 16;
             if (piece < WPIECES) GLDS4(wsrc + piece * 1024, lds_w + buf * WBYTES + piece * 1024);
         } else {
+            if (p.dbg & 2048) return;
             const int u = (slot - NWT) >> 1, plane = (slot - NWT) & 1;
             int piece = wave + u * 8;
             if (piece < XPIECES) {
@@ -171,7 +182,6 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
                     if (2 * tap < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap);
                     if (2 * tap + 1 < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap + 1);
                 }
-                if (tap + 1 < TAPS && !((p.dbg & 512) && it > 0)) load_step(tap + 1, (tap + 1) & 1);
                 __builtin_amdgcn_sched_barrier(0);
                 // the three partial products of one accumulator are issued four MFMAs apart (no back-to-back dependency);
                 // small terms first, as in conv3
@@ -180,6 +190,11 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
 #pragma unroll
                     for (int j = 0; j < WPX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
+                // The next tap's operands are requested only now, with 8 MFMAs still to issue in front of their first use:
+                // hipcc waits lgkmcnt(0) before a tap's first MFMA, so nothing younger may be in flight at that point.
+                __builtin_amdgcn_sched_barrier(0);
+                if (tap + 1 < TAPS) load_step(tap + 1, (tap + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -216,40 +231,59 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
         const int py = (pp >> p.ltw) & (TH - 1);
         const int ti = pp >> (p.ltw + p.lth);
         const int n = n0 + ti, y = ty0 + py, x = tx0 + px;
-        if (!(ti < TI && n < p.B && y < p.H && x < p.W)) return;
+        const bool img_ok = ti < TI && n < p.B;                       // wave uniform: a wave's 64 pixels share one image
+        const bool pok = img_ok && y < p.H && x < p.W;
+        if (!img_ok) return;
         const size_t pix = (size_t)y * p.W + x;
         float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
+        // GroupNorm statistics of the tensor being written, fused: this wave's 64-pixel partial sums go to its own slot
+        const bool do_stat = p.stat != nullptr && p.ksplit == 1;
+        const int wpi = (TW * TH) >> 6;                                // waves per image inside one tile
+        const int slot = trem * wpi + (wave & (wpi - 1));
 #pragma unroll 4
         for (int it = 0; it < 16; ++it) {
             const int co_l = it * 4 + rsub;
             const int co = co0 + co_l;
-            if (co >= p.Cout) continue;
-            float4 v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
-            const size_t plane = (size_t)n * p.Cout + co;
-            if (p.ksplit == 1) {
-                const float bv = p.bias[co];
-                v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                if (p.res) {
-                    if (p.res_mode == 0) {
-                        float4 rv = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
-                        v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
-                    } else if (p.res_mode == 1) {
-                        int Hr = p.H >> 1, Wr = p.W >> 1;
-                        float2 rv = *reinterpret_cast<const float2*>(p.res + plane * (Hr * Wr) + (y >> 1) * Wr + (x >> 1));
-                        v.x = rv.x + v.x; v.y = rv.x + v.y; v.z = rv.y + v.z; v.w = rv.y + v.w;
-                    } else {
-                        int Wr = p.W * 2;
-                        const float* rp = p.res + plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
-                        float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
-                        float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
-                        v.x = ((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f + v.x;
-                        v.y = ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f + v.y;
-                        v.z = ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f + v.z;
-                        v.w = ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f + v.w;
+            const bool cok = co < p.Cout;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok && pok) {
+                v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
+                const size_t plane = (size_t)n * p.Cout + co;
+                if (p.ksplit == 1) {
+                    const float bv = p.bias[co];
+                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                    if (p.res) {
+                        if (p.res_mode == 0) {
+                            float4 rv = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
+                            v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
+                        } else if (p.res_mode == 1) {
+                            int Hr = p.H >> 1, Wr = p.W >> 1;
+                            float2 rv = *reinterpret_cast<const float2*>(p.res + plane * (Hr * Wr) + (y >> 1) * Wr + (x >> 1));
+                            v.x = rv.x + v.x; v.y = rv.x + v.y; v.z = rv.y + v.z; v.w = rv.y + v.w;
+                        } else {
+                            int Wr = p.W * 2;
+                            const float* rp = p.res + plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
+                            float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
+                            float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
+                            v.x = ((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f + v.x;
+                            v.y = ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f + v.y;
+                            v.z = ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f + v.z;
+                            v.w = ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f + v.w;
+                        }
                     }
                 }
+                *reinterpret_cast<float4*>(dst + plane * HW + pix) = v;
             }
-            *reinterpret_cast<float4*>(dst + plane * HW + pix) = v;
+            if (do_stat) {
+                float s1 = (v.x + v.y) + (v.z + v.w);
+                float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                // inclusive scan over the 16-lane DPP row (row_shr 1, 2, 4, 8, zero fill): lane 15 of the row ends with the total
+                s1 += dpp_row_shr<0x111>(s1); s2 += dpp_row_shr<0x111>(s2);
+                s1 += dpp_row_shr<0x112>(s1); s2 += dpp_row_shr<0x112>(s2);
+                s1 += dpp_row_shr<0x114>(s1); s2 += dpp_row_shr<0x114>(s2);
+                s1 += dpp_row_shr<0x118>(s1); s2 += dpp_row_shr<0x118>(s2);
+                if (q4 == 15 && cok) p.stat[((size_t)n * p.Cout + co) * p.stat_slots + slot] = make_float2(s1, s2);
+            }
         }
         return;
     }
@@ -326,11 +360,22 @@ bool conv4_supported(int H, int W) {
     int hp2 = 1 << ilog2e(H);
     if (th > hp2) th = hp2;
     int ti = 512 / (tw * th);
-    if (ti > 8) return false;
+    if (ti > 8 || tw * th < 64) return false;
     return ti * (th + 2) * (tw + 2) <= 648;
 }
 
-Status launch_conv4(hipStream_t s, const Conv4Args& a) {
+// number of statistics slots per (image, channel) plane that launch_conv4 fills when Conv4Args::stat is set
+int conv4_stat_slots(int H, int W) {
+    if (!conv4_supported(H, W) || (W & 3)) return 0;
+    int tw = W >= 32 ? 32 : 16;
+    int th = 512 / tw;
+    int hp2 = 1 << ilog2e(H);
+    if (th > hp2) th = hp2;
+    return ((W + tw - 1) / tw) * ((H + th - 1) / th) * ((tw * th) >> 6);
+}
+
+Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written) {
+    if (stat_written) *stat_written = false;
     if (!conv4_supported(a.H, a.W)) return Status{DPIR_ERR_UNSUPPORTED, "conv4: shape not tiled"};
     Conv4K k;
     k.xhi = reinterpret_cast<const char*>(a.xhi); k.xlo = reinterpret_cast<const char*>(a.xlo); k.C8 = (a.Cin + 7) / 8;
@@ -370,6 +415,11 @@ Status launch_conv4(hipStream_t s, const Conv4Args& a) {
         if ((size_t)S * k.B * k.Cout * k.H * k.W > a.partial_capacity) S = 1;
     }
     k.ksplit = S;
+    k.stat = nullptr; k.stat_slots = 0;
+    if (a.stat && S == 1 && (a.dbg & 16) == 0) {
+        k.stat_slots = conv4_stat_slots(a.H, a.W);
+        if (k.stat_slots > 0) { k.stat = a.stat; if (stat_written) *stat_written = true; }
+    }
     k.chunks_per_split = (chunks + S - 1) / S;
     if (S == 1) k.partial = nullptr;
     hipLaunchKernelGGL(conv4_mfma_kernel, dim3((unsigned)(blocks * S)), dim3(512), LDS, s, k);

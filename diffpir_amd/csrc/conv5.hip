@@ -42,8 +42,9 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int half = lane >> 5;
-    const int co_blk = blockIdx.x % p.n_co_blocks;
-    const long long px0 = (long long)(blockIdx.x / p.n_co_blocks) * 256;
+    const int bid = blockIdx.x;             // plain order: measured faster than the XCD renumbering conv4.hip uses
+    const int co_blk = bid % p.n_co_blocks;
+    const long long px0 = (long long)(bid / p.n_co_blocks) * 256;
     const int C = p.ca + p.cb;
     const int HW = p.HW;
 

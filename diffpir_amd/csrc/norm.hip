@@ -62,42 +62,68 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(CatSrc src, int HW, doubl
 
 Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part) {
     int C = src.ca + src.cb;
-    if (C % 32) return invalid("GroupNorm32 needs channels % 32 == 0");
     hipLaunchKernelGGL(gn_stats_kernel, dim3(B * C), dim3(256), 0, s, src, HW, part);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
-__global__ void gn_prm_kernel(const double2* part, int HW, const float* gamma, const float* beta, const float* film,
-                              int film_stride, int film_off, int B, int C, float act, float4* prm) {
-    int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * C) return;
-    int n = i / C, c = i - n * C;
+// One workgroup per (image, group): folds the group's per-channel statistics in fp64 - conv4 epilogue slots
+// (float2 per 64-pixel wave) or gn_stats partials (double2 per plane), per source tensor of the virtual concat - in a
+// fixed order (thread-strided, then the usual wave/LDS tree), and writes the per-channel affine parameters.
+__global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
+                                                     const float* film, int film_stride, int film_off, int C, float act, float4* prm) {
+    const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
     const int cg = C / 32;
-    const double2* pg = part + (size_t)n * C + (c / cg) * cg;
     double S = 0.0, SS = 0.0;
-    for (int k = 0; k < cg; ++k) { S += pg[k].x; SS += pg[k].y; }
-    double cnt = (double)cg * HW;
-    double mean = S / cnt;
-    double var = SS / cnt - mean * mean;
-    if (var < 0) var = 0;
-    float2 st = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
-    float a = st.y * gamma[c];
-    float b = beta[c];
-    if (film) {   // h = GN(h) * (1 + scale) + shift   (unet.py:250-251)
-        float sc = 1.0f + film[(size_t)n * film_stride + film_off + c];
-        float sh = film[(size_t)n * film_stride + film_off + C + c];
-        a = a * sc;
-        b = b * sc + sh;
+    for (int k = 0; k < cg; ++k) {
+        const int c = g * cg + k;
+        const bool in_a = c < sa.c;
+        const GnStatSrc& src = in_a ? sa : sb;
+        const int cl = in_a ? c : c - sa.c;
+        if (src.slots) {
+            const float2* sp = src.slots + ((size_t)n * src.c + cl) * src.nslots;
+            for (int i = threadIdx.x; i < src.nslots; i += 256) { float2 v = sp[i]; S += (double)v.x; SS += (double)v.y; }
+        } else if (threadIdx.x == 0) {
+            double2 v = src.part[(size_t)n * src.c + cl];
+            S += v.x; SS += v.y;
+        }
     }
-    prm[i] = make_float4(st.x, a, b, act);
+    __shared__ double red[2][4];
+    __shared__ float2 st_sh;
+    S = wave_sum(S); SS = wave_sum(SS);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[0][w] = S; red[1][w] = SS; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        double ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        double cnt = (double)cg * HW;
+        double mean = s / cnt;
+        double var = ss / cnt - mean * mean;
+        if (var < 0) var = 0;
+        st_sh = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+    }
+    __syncthreads();
+    const float2 st = st_sh;
+    for (int k = threadIdx.x; k < cg; k += 256) {
+        const int c = g * cg + k;
+        float a = st.y * gamma[c];
+        float b = beta[c];
+        if (film) {   // h = GN(h) * (1 + scale) + shift   (unet.py:250-251)
+            float sc = 1.0f + film[(size_t)n * film_stride + film_off + c];
+            float sh = film[(size_t)n * film_stride + film_off + C + c];
+            a = a * sc;
+            b = b * sc + sh;
+        }
+        prm[(size_t)n * C + c] = make_float4(st.x, a, b, act);
+    }
 }
 
-Status launch_gn_prm(hipStream_t s, const double2* part, int HW, const float* gamma, const float* beta,
+Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
                      const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm) {
-    int n = B * C;
-    hipLaunchKernelGGL(gn_prm_kernel, dim3((n + 255) / 256), dim3(256), 0, s, part, HW, gamma, beta, film, film_stride,
-                       film_off, B, C, silu ? 1.0f : 0.0f, prm);
+    if (C % 32 || sa.c + sb.c != C) return invalid("gn_prm: channel bookkeeping");
+    hipLaunchKernelGGL(gn_prm_kernel, dim3(B * 32), dim3(256), 0, s, sa, sb, HW, gamma, beta, film, film_stride,
+                       film_off, C, silu ? 1.0f : 0.0f, prm);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -7,6 +7,8 @@
 // attn.hip; concat, pooling, upsampling, GroupNorm-apply, SiLU, FiLM, bias and residual adds never
 // exist as separate passes (see conv.hip).
 #include "engine.h"
+#include <unordered_map>
+#include <cstdint>
 #include <math.h>
 #include <string.h>
 
@@ -271,6 +273,9 @@ struct Fwd {
     int film_rows;
     float* partial;        // split-K slab shared by all convolutions of the forward
     size_t partial_cap;
+    // GroupNorm statistics already produced by the epilogue of the convolution that wrote a tensor (keyed by its address)
+    struct FusedStat { const float2* slots; int nslots; };
+    std::unordered_map<const float*, FusedStat> fused;
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
         if (cw.w16 && cw.ks == 3 && conv4_supported(Ho, Wo)) {
@@ -291,16 +296,25 @@ struct Fwd {
             a4.bias = cw.bias; a4.out = out; a4.res = res; a4.res_mode = res_mode;
             a4.B = B; a4.Cin = cw.cin; a4.Cout = cw.cout; a4.H = Ho; a4.W = Wo;
             a4.partial = partial; a4.partial_capacity = partial_cap;
+            const int slots = conv4_stat_slots(Ho, Wo);
+            float2* st = nullptr;
+            if (slots > 0 && cw.cout % 32 == 0) DPIR_TRY(ws.getT("st#" + std::to_string(reinterpret_cast<uintptr_t>(out)), (size_t)B * cw.cout * slots, &st));
+            a4.stat = st;
+            bool wrote = false;
             ProfScope ps(&e->prof, PC_CONV3);
-            return launch_conv4(s, a4);
+            DPIR_TRY(launch_conv4(s, a4, &wrote));
+            if (wrote) fused[out] = FusedStat{st, slots}; else fused.erase(out);
+            return Status{};
         }
         if (cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo)) {
             Conv5Args a5;
             a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
             a5.bias = cw.bias; a5.out = out; a5.res = res; a5.B = B; a5.Cout = cw.cout; a5.H = Ho; a5.W = Wo;
+            fused.erase(out);
             ProfScope ps(&e->prof, PC_CONV1);
             return launch_conv5(s, a5);
         }
+        fused.erase(out);
         ConvArgs a;
         a.src.a = in.a; a.src.ca = in.ca; a.src.b = in.b; a.src.cb = in.cb; a.src.Hs = in.H; a.src.Ws = in.W;
         a.src.mode = mode; a.src.prm = prm;
@@ -312,15 +326,24 @@ struct Fwd {
         return launch_conv(s, a);
     }
     Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out) {
-        double2* stats = nullptr; float4* prm = nullptr;
-        DPIR_TRY(ws.getT(tag + "#stats", (size_t)B * g.c, &stats));
+        float4* prm = nullptr;
         DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * g.c, &prm));
-        {
+        GnStatSrc src[2];
+        const float* tp[2] = {in.a, in.b};
+        const int tc[2] = {in.ca, in.cb};
+        for (int k = 0; k < 2; ++k) {
+            src[k].c = tc[k];
+            if (!tp[k] || tc[k] == 0) { src[k].c = 0; continue; }
+            auto it = fused.find(tp[k]);
+            if (it != fused.end()) { src[k].slots = it->second.slots; src[k].nslots = it->second.nslots; continue; }
+            double2* part = nullptr;     // this tensor was not written by a statistics-fusing kernel: one streaming pass
+            DPIR_TRY(ws.getT(tag + "#stats" + std::to_string(k), (size_t)B * tc[k], &part));
             ProfScope ps(&e->prof, PC_GN);
-            DPIR_TRY(launch_gn_stats(s, CatSrc{in.a, in.ca, in.b, in.cb}, B, in.H * in.W, stats));
+            DPIR_TRY(launch_gn_stats(s, CatSrc{tp[k], tc[k], nullptr, 0}, B, in.H * in.W, part));
+            src[k].part = part;
         }
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_gn_prm(s, stats, in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
+        DPIR_TRY(launch_gn_prm(s, src[0], src[1], in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
         *prm_out = prm;
         return Status{};
     }

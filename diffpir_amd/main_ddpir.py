@@ -132,6 +132,7 @@ def main(argv=None):
     config = parse_config(args.opt)
     np.random.seed(config.seed)
     eng = Engine(args.device)
+    eng.set_precision(str(config.get("engine_precision", "f16x3")))      # before load_state_dict: selects the weight packing
 
     model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
                         num_channels=128, num_res_blocks=1, attention_resolutions="16") \

@@ -8,6 +8,7 @@ from diffpir_amd import script_util, weights, synth, utils_sisr as sr
 
 B = int(os.environ.get("PROF_B", "16"))
 eng = diffpir_amd.Engine(0)
+eng.set_precision(os.environ.get("DIFFPIR_PRECISION", "f16x3"))
 hp = weights.model_hp("ffhq")
 model = script_util.create_model(**weights.create_model_kwargs(hp), engine=eng)
 model.load_state_dict(weights.synth_state_dict(hp, 0))
