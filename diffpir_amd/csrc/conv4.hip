@@ -215,6 +215,23 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     // (4 channel rows x 256 B per instruction) instead of 64 scalar stores per lane.
     if ((p.W & 3) == 0 && !(p.dbg & 16)) {
         constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
+        // Same-resolution residual: all 16 float4 loads of this lane are requested up front, so their latency is paid
+        // once (and overlaps the transpose) instead of once per unrolled batch of the store loop.
+        const bool pre_res = p.res != nullptr && p.res_mode == 0 && p.ksplit == 1;
+        float4 rpre[16];
+        {
+            const int q4 = lane & 15, rsub = lane >> 4;
+            const int pp = wave * 64 + q4 * 4;
+            const int ti = pp >> (p.ltw + p.lth);
+            const int n = n0 + ti, y = ty0 + ((pp >> p.ltw) & (TH - 1)), x = tx0 + (pp & (TW - 1));
+            const bool ok = pre_res && ti < TI && n < p.B && y < p.H && x < p.W;
+#pragma unroll
+            for (int it = 0; it < 16; ++it) {
+                const int co = co0 + it * 4 + rsub;
+                rpre[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok && co < p.Cout) rpre[it] = *reinterpret_cast<const float4*>(p.res + ((size_t)n * p.Cout + co) * HW + (size_t)y * p.W + x);
+            }
+        }
         __syncthreads();                                         // operand buffers are dead from here on
         float* tr = reinterpret_cast<float*>(smem4) + wave * (64 * TS);
 #pragma unroll
@@ -240,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
         const bool do_stat = p.stat != nullptr && p.ksplit == 1;
         const int wpi = (TW * TH) >> 6;                                // waves per image inside one tile
         const int slot = trem * wpi + (wave & (wpi - 1));
-#pragma unroll 4
+#pragma unroll
         for (int it = 0; it < 16; ++it) {
             const int co_l = it * 4 + rsub;
             const int co = co0 + co_l;
@@ -254,7 +271,7 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
                     v.x += bv; v.y += bv; v.z += bv; v.w += bv;
                     if (p.res) {
                         if (p.res_mode == 0) {
-                            float4 rv = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
+                            const float4 rv = rpre[it];
                             v.x = rv.x + v.x; v.y = rv.y + v.y; v.z = rv.z + v.z; v.w = rv.w + v.w;
                         } else if (p.res_mode == 1) {
                             int Hr = p.H >> 1, Wr = p.W >> 1;
@@ -352,26 +369,33 @@ const float* conv_zero_page();
 
 static int ilog2e(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
-// geometry shared with the executor: does conv4 tile this output shape?
-bool conv4_supported(int H, int W) {
-    if (W < 16) return false;
-    int tw = W >= 32 ? 32 : 16;
-    int th = 512 / tw;
+// Tile geometry: a 512-pixel tile is TI images x TH rows x TW columns (all powers of two; lanes beyond the image or beyond
+// TI are masked).  TI is cut down when the TI halo patches would not fit the 648-entry plane (8x8 layers: 6 images).
+struct Conv4Geo { int tw, th, ti, slots; bool ok; };
+static Conv4Geo conv4_geometry(int H, int W) {
+    Conv4Geo g{0, 0, 0, 0, false};
+    if (W < 8 || H < 8) return g;
+    g.tw = W >= 32 ? 32 : (W >= 16 ? 16 : 8);
+    g.th = 512 / g.tw;
     int hp2 = 1 << ilog2e(H);
-    if (th > hp2) th = hp2;
-    int ti = 512 / (tw * th);
-    if (ti > 8 || tw * th < 64) return false;
-    return ti * (th + 2) * (tw + 2) <= 648;
+    if (g.th > hp2) g.th = hp2;
+    if (g.tw * g.th < 64) return g;                   // a wave's 64 pixels must belong to one image
+    g.ti = 512 / (g.tw * g.th);
+    const int patch = (g.th + 2) * (g.tw + 2);
+    if (g.ti * patch > 648) g.ti = 648 / patch;
+    if (g.ti < 1 || g.ti > 8) return g;
+    g.slots = ((W + g.tw - 1) / g.tw) * ((H + g.th - 1) / g.th) * ((g.tw * g.th) >> 6);
+    g.ok = true;
+    return g;
 }
+
+// geometry shared with the executor: does conv4 tile this output shape?
+bool conv4_supported(int H, int W) { return conv4_geometry(H, W).ok; }
 
 // number of statistics slots per (image, channel) plane that launch_conv4 fills when Conv4Args::stat is set
 int conv4_stat_slots(int H, int W) {
-    if (!conv4_supported(H, W) || (W & 3)) return 0;
-    int tw = W >= 32 ? 32 : 16;
-    int th = 512 / tw;
-    int hp2 = 1 << ilog2e(H);
-    if (th > hp2) th = hp2;
-    return ((W + tw - 1) / tw) * ((H + th - 1) / th) * ((tw * th) >> 6);
+    Conv4Geo g = conv4_geometry(H, W);
+    return (g.ok && (W & 3) == 0) ? g.slots : 0;
 }
 
 Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written) {
@@ -387,11 +411,8 @@ Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written) {
     k.out_scale = 1.0f / a.w16_scale;
     k.zeros = conv_zero_page();
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv4: cannot allocate the zero page"};
-    int tw = a.W >= 32 ? 32 : 16;
-    int th = 512 / tw;
-    int hp2 = 1 << ilog2e(a.H);
-    if (th > hp2) th = hp2;
-    int ti = 512 / (tw * th);
+    const Conv4Geo geo = conv4_geometry(a.H, a.W);
+    const int tw = geo.tw, th = geo.th, ti = geo.ti;
     k.ti = ti; k.ltw = ilog2e(tw); k.lth = ilog2e(th);
     k.tiles_x = (a.W + tw - 1) / tw;
     k.tiles_y = (a.H + th - 1) / th;

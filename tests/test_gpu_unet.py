@@ -105,6 +105,19 @@ def test_f16x3_mode_full_size_and_fixture(engine_f16x3, golden):
     assert rel_err(o, g["out"]) < 1e-5
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_imagenet256_topology_64(precision):
+    """BASELINE configs C3/C5 topology (256x256_diffusion_uncond: 552.8 M parameters, 256 base channels, two ResBlocks per
+    level, attention at 32/16/8, learn_sigma) at a 64x64 input, layer by layer against the oracle, both arithmetic modes."""
+    import diffpir_amd
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision(precision)
+        _run_and_compare(e, uo.imagenet256_hp(), 2, 64, 64)
+    finally:
+        e.close()
+
+
 def test_missing_weight_is_reported(engine):
     import diffpir_amd
     from diffpir_amd import script_util
