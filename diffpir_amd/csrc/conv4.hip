@@ -146,36 +146,45 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
 
 #pragma unroll
     for (int sl = 0; sl < NSLOT; ++sl) issue_slot(ch_begin, 0, sl);
+    // Software pipeline across K chunks.  The only workgroup barrier of a chunk sits INSIDE its last tap, between the first
+    // MFMA group and the other two: at that point every wave has issued (and, because __syncthreads drains lgkmcnt,
+    // completed) all LDS reads of the current buffer, and has waited for its own DMA pieces of the next one, so after the
+    // barrier (a) the next chunk's tap-0 operands can be requested while 8 MFMAs are still queued - the MFMA pipe never
+    // drains at a chunk boundary - and (b) the current buffer is free for the DMA of the chunk after next.
+    const half8* wbase = reinterpret_cast<const half8*>(lds_w);
+    const half8* xbase = reinterpret_cast<const half8*>(lds_x);
+    half8 ah[2][WCO], al[2][WCO], bh[2][WPX], bl[2][WPX];
+    auto load_step = [&](int lbuf, int tap, int rbuf) {
+        const half8* wh = wbase + lbuf * (WBYTES / 16);
+        const half8* wl = wh + WBYTES / 32;
+        const half8* xh = xbase + lbuf * (2 * XBYTES / 16);
+        const half8* xl = xh + XBYTES / 16;
+        const int toff = (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int i = 0; i < WCO; ++i) {
+            int o = tap * 2 * BCO + aoff + i * 32;
+            ah[rbuf][i] = wh[o]; al[rbuf][i] = wl[o];
+        }
+#pragma unroll
+        for (int j = 0; j < WPX; ++j) {
+            int o = boff[j] + toff;
+            bh[rbuf][j] = xh[o]; bl[rbuf][j] = xl[o];
+        }
+    };
+    __syncthreads();                        // chunk ch_begin has landed (vmcnt(0) precedes the barrier)
+    if (!(p.dbg & 1)) load_step(0, 0, 0);
     int it = 0;
     for (int chunk = ch_begin; chunk < ch_end; ++chunk, ++it) {
         const int cur = it & 1;
-        __syncthreads();                    // every wave's DMAs of this chunk have landed (vmcnt(0) precedes the barrier)
         const bool more = chunk + 1 < ch_end;
 
-        if (p.dbg & 1) {
-            if (more)
+        if (p.dbg & 1) {                    // ablation: DMA only
+            if (more) {
 #pragma unroll
                 for (int sl = 0; sl < NSLOT; ++sl) issue_slot(chunk + 1, cur ^ 1, sl);
+                __syncthreads();
+            }
         } else {
-            const half8* wh = reinterpret_cast<const half8*>(lds_w + cur * WBYTES);
-            const half8* wl = wh + WBYTES / 32;
-            const half8* xh = reinterpret_cast<const half8*>(lds_x + cur * 2 * XBYTES);
-            const half8* xl = xh + XBYTES / 16;
-            half8 ah[2][WCO], al[2][WCO], bh[2][WPX], bl[2][WPX];
-            auto load_step = [&](int tap, int buf) {
-                const int toff = (tap / 3) * LW + (tap % 3);
-#pragma unroll
-                for (int i = 0; i < WCO; ++i) {
-                    int o = tap * 2 * BCO + aoff + i * 32;
-                    ah[buf][i] = wh[o]; al[buf][i] = wl[o];
-                }
-#pragma unroll
-                for (int j = 0; j < WPX; ++j) {
-                    int o = boff[j] + toff;
-                    bh[buf][j] = xh[o]; bl[buf][j] = xl[o];
-                }
-            };
-            load_step(0, 0);
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 if (more) {
@@ -193,7 +202,12 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
                 // The next tap's operands are requested only now, with 8 MFMAs still to issue in front of their first use:
                 // hipcc waits lgkmcnt(0) before a tap's first MFMA, so nothing younger may be in flight at that point.
                 __builtin_amdgcn_sched_barrier(0);
-                if (tap + 1 < TAPS) load_step(tap + 1, (tap + 1) & 1);
+                if (tap + 1 < TAPS) {
+                    load_step(cur, tap + 1, (tap + 1) & 1);
+                } else if (more) {
+                    __syncthreads();
+                    load_step(cur ^ 1, 0, 1);            // tap 8 computes from register set 0; copied to set 0 below
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < WCO; ++i)
@@ -206,6 +220,12 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
                     for (int j = 0; j < WPX; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[tap & 1][i], bh[tap & 1][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < WCO; ++i) { ah[0][i] = ah[1][i]; al[0][i] = al[1][i]; }
+#pragma unroll
+                for (int j = 0; j < WPX; ++j) { bh[0][j] = bh[1][j]; bl[0][j] = bl[1][j]; }
             }
         }
     }
