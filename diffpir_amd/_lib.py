@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libdiffpir_hip.so")
+# DIFFPIR_LIB: developer override used to A/B kernel variants on one GPU box; the default is the in-tree build
+LIB_PATH = os.environ.get("DIFFPIR_LIB") or os.path.join(_HERE, "csrc", "libdiffpir_hip.so")
 
 
 class UNetDesc(C.Structure):

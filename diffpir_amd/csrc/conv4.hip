@@ -14,6 +14,10 @@ namespace dpir {
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
 
+#ifndef DMA_SLOTS_PER_TAP
+#define DMA_SLOTS_PER_TAP 2
+#endif
+
 struct Conv4K {
     const char* xhi; const char* xlo;      // blocked split activations [n][C8][H][W][16 B]
     int C8;
@@ -188,8 +192,10 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
 #pragma unroll
             for (int tap = 0; tap < TAPS; ++tap) {
                 if (more) {
-                    if (2 * tap < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap);
-                    if (2 * tap + 1 < NSLOT) issue_slot(chunk + 1, cur ^ 1, 2 * tap + 1);
+                    constexpr int SPT = DMA_SLOTS_PER_TAP;
+#pragma unroll
+                    for (int q = 0; q < SPT; ++q)
+                        if (SPT * tap + q < NSLOT) issue_slot(chunk + 1, cur ^ 1, SPT * tap + q);
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 // the three partial products of one accumulator are issued four MFMAs apart (no back-to-back dependency);

@@ -17,6 +17,7 @@ for name, (Cin, Cout, H, ks) in {"c3 128->128@256": (128, 128, 256, 3), "c3 256-
                                  "c3 256->256@64": (256, 256, 64, 3), "c3 512->512@16": (512, 512, 16, 3), "c3 512->512@8": (512, 512, 8, 3),
                                  "c1 256->128@256": (256, 128, 256, 1), "c1 384->128@128": (384, 128, 128, 1), "c1 768->256@64": (768, 256, 64, 1), "c1 512->1536@16": (512, 1536, 16, 1)}.items():
     print(f"== {name} B={B}")
+    only = os.environ.get("ABL_ONLY")
     rows1 = (("fp32 conv2 prm=null", 0, 0), ("conv5 prm=null", 64 | 128, 0), ("fp32 conv2 with prm", 0, 1), ("conv5 with prm", 64 | 128, 1))
     for label, dbg, prm in rows1 if ks == 1 else (("full", 0, 1), ("conv4 + act_split", 64 | 128, 1), ("conv4 alone", 64 | 128 | 256, 1), ("conv4 alone, no chunk barrier (invalid results)", 64 | 128 | 256 | 8192, 1), ("conv4 MFMA only, no chunk barrier", 64 | 128 | 256 | 4 | 16 | 8192, 1),
                             ("conv4 no weight DMA", 64 | 128 | 256 | 1024, 1), ("conv4 no activation DMA", 64 | 128 | 256 | 2048, 1), ("conv4 no weight DMA, no epilogue", 64 | 128 | 256 | 1024 | 16, 1), ("conv4 no act DMA, no epilogue", 64 | 128 | 256 | 2048 | 16, 1), ("conv4 MFMA only", 64 | 128 | 256 | 4 | 16, 1), ("conv4 no MFMA", 64 | 128 | 256 | 1, 1),
@@ -25,5 +26,7 @@ for name, (Cin, Cout, H, ks) in {"c3 128->128@256": (128, 128, 256, 3), "c3 256-
                             ("no global loads", 4, 1), ("no LDS stores", 8, 1), ("no epilogue", 16, 1),
                             ("MFMA only (4|8|2|16)", 4 | 8 | 2 | 16, 1), ("no MFMA, no loads", 1 | 4, 1),
                             ("no MFMA no loads no lds", 1 | 4 | 8, 1)):
+        if only and only not in label:
+            continue
         ms, tf = run(B, Cin, Cout, H, ks, 0, prm, dbg)
         print(f"   {label:48s} {ms*1e3:9.1f} us   {tf:7.1f} TF-equivalent")
