@@ -724,7 +724,7 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         if (!(dbg & 256)) API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, s16, s16 + plane));
         a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = a.w16; a4.w16_scale = a.w16_scale; a4.bias = bias; a4.out = out;
         a4.B = B; a4.Cin = Cin; a4.Cout = Cout; a4.H = H; a4.W = W; a4.partial = partial; a4.partial_capacity = a.partial_capacity;
-        a4.dbg = (dbg & 31) | (dbg & (1024 | 2048 | 8192));
+        a4.dbg = (dbg & 31) | (dbg & (1024 | 2048));
     }
     auto run_once = [&]() -> Status {
         if (use5) return launch_conv5(e->stream, a5);

@@ -187,21 +187,29 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
     for (int n1 = 0; n1 < R; ++n1) v[n1] = z[R * n1 + t];
     __syncthreads();
     fft_two_pass<R, true>(v, t, xch + slot * R * (R + 1), twN);
+    // stage the block's 2*SLOTS real rows in LDS, then float4 row-contiguous stores (a lane-strided direct store writes
+    // 64-byte fragments of 8 different rows per instruction)
+    float* stage = reinterpret_cast<float*>(zbuf);          // [2*SLOTS][N + 4] floats (the z area is dead now)
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) {
         int n = t + R * k2;
-        if (va) {
-            size_t gi = ra * N + n;
-            float val = (v[k2].x * scale) * oa + ob;
-            if (blend_base) { float b0 = blend_base[gi]; val = b0 + g * (val - b0); }
-            out[gi] = val;
+        stage[(2 * slot) * (N + 4) + n] = (v[k2].x * scale) * oa + ob;
+        stage[(2 * slot + 1) * (N + 4) + n] = (v[k2].y * scale) * oa + ob;
+    }
+    __syncthreads();
+    const size_t row0 = (size_t)blockIdx.x * SLOTS * 2;
+    constexpr int V4 = N / 4;
+    for (int i = threadIdx.x; i < 2 * SLOTS * V4; i += THREADS) {
+        int r = i / V4, c4 = i - r * V4;
+        size_t row = row0 + r;
+        if (row >= total_rows) continue;
+        float4 q = *reinterpret_cast<const float4*>(stage + r * (N + 4) + c4 * 4);
+        size_t gi = row * N + c4 * 4;
+        if (blend_base) {
+            float4 b0 = *reinterpret_cast<const float4*>(blend_base + gi);
+            q.x = b0.x + g * (q.x - b0.x); q.y = b0.y + g * (q.y - b0.y); q.z = b0.z + g * (q.z - b0.z); q.w = b0.w + g * (q.w - b0.w);
         }
-        if (vb) {
-            size_t gi = rb * N + n;
-            float val = (v[k2].y * scale) * oa + ob;
-            if (blend_base) { float b0 = blend_base[gi]; val = b0 + g * (val - b0); }
-            out[gi] = val;
-        }
+        *reinterpret_cast<float4*>(out + gi) = q;
     }
 }
 
@@ -272,14 +280,15 @@ __global__ void psf_embed_real_kernel(const float* k, int kh, int kw, float* out
 
 // ------------------------------------------------------------------------------------------------ launchers
 bool fft2_supported(int H, int W, int sf) { return sf == 1 && H == W && (H == 256 || H == 64); }
-int fft2_padded_width(int W) { int cs = (W == 256) ? 8 : 16; return (W / 2 + 1 + cs - 1) / cs * cs; }   // multiple of the column strip
+int fft2_padded_width(int W) { const int cs = 16; return (W / 2 + 1 + cs - 1) / cs * cs; }   // multiple of the column strip
 
 constexpr int ROW_THREADS = 64;    // small workgroups: at B = 16 the whole prox is ~40 MB, concurrency comes from block count
-constexpr int COL_THREADS = 128;
+// 16 columns per strip for both sizes: a strip row is one full 128-byte line (8 columns = half lines cost ~2x the requests)
+template <int R> struct ColCfg { static constexpr int THREADS = 16 * R; };
 template <int R>
 static size_t rows_lds() { return (size_t)(R * R + (ROW_THREADS / R) * R * (R + 1) + (ROW_THREADS / R) * (R * R + 4)) * sizeof(float2); }
 template <int R>
-static size_t cols_lds() { return (size_t)(R * R + (COL_THREADS / R) * (R * (R + 1) + 1)) * sizeof(float2); }
+static size_t cols_lds() { return (size_t)(R * R + (ColCfg<R>::THREADS / R) * (R * (R + 1) + 1)) * sizeof(float2); }
 
 template <int R>
 static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
@@ -322,6 +331,7 @@ Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, flo
 template <int R, int MODE>
 static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P, int N, const float2* tw) {
     int WP = fft2_padded_width(N);
+    constexpr int COL_THREADS = ColCfg<R>::THREADS;
     constexpr int CS = COL_THREADS / R;
     auto fn = cfft_cols_kernel<R, MODE, COL_THREADS>;
     static bool attr = false;

@@ -19,7 +19,7 @@ for name, (Cin, Cout, H, ks) in {"c3 128->128@256": (128, 128, 256, 3), "c3 256-
     print(f"== {name} B={B}")
     only = os.environ.get("ABL_ONLY")
     rows1 = (("fp32 conv2 prm=null", 0, 0), ("conv5 prm=null", 64 | 128, 0), ("fp32 conv2 with prm", 0, 1), ("conv5 with prm", 64 | 128, 1))
-    for label, dbg, prm in rows1 if ks == 1 else (("full", 0, 1), ("conv4 + act_split", 64 | 128, 1), ("conv4 alone", 64 | 128 | 256, 1), ("conv4 alone, no chunk barrier (invalid results)", 64 | 128 | 256 | 8192, 1), ("conv4 MFMA only, no chunk barrier", 64 | 128 | 256 | 4 | 16 | 8192, 1),
+    for label, dbg, prm in rows1 if ks == 1 else (("full", 0, 1), ("conv4 + act_split", 64 | 128, 1), ("conv4 alone", 64 | 128 | 256, 1),
                             ("conv4 no weight DMA", 64 | 128 | 256 | 1024, 1), ("conv4 no activation DMA", 64 | 128 | 256 | 2048, 1), ("conv4 no weight DMA, no epilogue", 64 | 128 | 256 | 1024 | 16, 1), ("conv4 no act DMA, no epilogue", 64 | 128 | 256 | 2048 | 16, 1), ("conv4 MFMA only", 64 | 128 | 256 | 4 | 16, 1), ("conv4 no MFMA", 64 | 128 | 256 | 1, 1),
                             ("conv4 no epilogue", 64 | 128 | 256 | 16, 1), ("conv4 no DMA", 64 | 128 | 256 | 4, 1), ("f16x3 full", 64, 1), ("f16x3 no transform", 64 | 2, 1), ("f16x3 no MFMA", 64 | 1, 1),
                             ("f16x3 MFMA only", 64 | 4 | 8 | 2 | 16, 1), ("f16x3 no loads", 64 | 4, 1), ("f16x3 no epilogue", 64 | 16, 1), ("no prologue transform", 2, 1), ("prm=null", 0, 0), ("no MFMA", 1, 1),
