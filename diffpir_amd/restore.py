@@ -66,10 +66,13 @@ class LoopConfig:
         raise ValueError(f"unknown task {self.task}")
 
     def check_supported(self):
+        # ddim_sample is accepted: with model_output_type=pred_xstart it selects the same x0 prediction and the same number
+        # of RNG draws as p_sample (utils_model.py:219-240; tests/golden/model_fn.npz).  iter_num_U > 1 cannot be mirrored:
+        # the reference raises IndexError on `seq[i+1]` at its last step (main_ddpir.py:448-451 with u < iter_num_U-1).
         if self.generate_mode != "DiffPIR" or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
-                or self.ddim_sample or self.iter_num_U != 1:
+                or self.iter_num_U != 1:
             raise NotImplementedError("only generate_mode=DiffPIR, model_output_type=pred_xstart, sub_1_analytic=true, "
-                                      "ddim_sample=false, iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
+                                      "iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
 
 
 def _steps(cfg: LoopConfig):

@@ -21,8 +21,9 @@ from .script_util import add_dict_to_argparser
 
 def model_fn(x, noise_level, model_diffusion, vec_t=None, model_out_type='pred_xstart',
              diffusion=None, ddim_sample=False, alphas_cumprod=None, **model_kwargs):
-    if ddim_sample:
-        raise NotImplementedError("ddim_sample=True is outside the accelerated path (SURVEY.md 8f rank 3)")
+    # ddim_sample=True (utils_model.py:230-240 -> gaussian_diffusion.py:537-585, eta=0): 'pred_xstart' is the very same
+    # p_mean_variance output as in p_sample and one randn_like is consumed either way, so the flag does not change this
+    # path (pinned against the live reference in tests/golden/model_fn.npz).
     if model_out_type not in ("pred_xstart", "epsilon"):
         raise NotImplementedError(f"model_out_type={model_out_type!r}: only the DiffPIR analytic path "
                                   f"('pred_xstart') is accelerated")

@@ -130,7 +130,8 @@ def pred_xstart_from_eps(x, eps, t: int, dtab: DiffusionTables):
 
 def model_fn_xstart(sd, hp, x, noise_level, dt: DriverTables, dtab: DiffusionTables,
                     noise_fn: Optional[Callable] = None, y_label=None):
-    """utils_model.py:207-258 with model_out_type='pred_xstart', ddim_sample=False.
+    """utils_model.py:207-258 with model_out_type='pred_xstart'; ddim_sample False or True (eta=0) give the same x0 and the
+    same single randn_like draw (gaussian_diffusion.py:395-439 vs 537-585; pinned by tests/golden/model_fn.npz).
     noise_fn(x) mirrors the (dead but RNG-consuming) randn_like in p_sample (gaussian_diffusion.py:430)."""
     t_step = find_nearest(dt.reduced, noise_level / 255.0)
     vec_t = torch.tensor([t_step] * x.shape[0])

@@ -149,3 +149,18 @@ def test_model_fn_plug_matches_oracle(engine):
         ref = do.model_fn_xstart(sd, hp, x, sig * 255, odt, odtab).numpy()
         assert np.abs(x0 - ref).max() < 5e-4
         assert x0.min() >= -1 and x0.max() <= 1
+
+
+def test_model_fn_ddim_flag_matches_live_reference_fixture(engine, golden):
+    """ddim_sample=True is accepted and equals the live reference's pred_xstart (tests/golden/model_fn.npz)."""
+    from diffpir_amd import utils_model, script_util, schedule
+    g = golden("model_fn")
+    model, _ = make_model(engine, uo.tiny_hp())
+    diffusion = script_util.create_gaussian_diffusion(steps=1000, learn_sigma=True)
+    dt = schedule.DriverTables.make()
+    for j, sig in enumerate(g["noise_levels"]):
+        for ddim in (False, True):
+            x0 = utils_model.model_fn(engine.to_device(g["x"]), noise_level=float(sig) * 255, model_out_type="pred_xstart",
+                                      model_diffusion=model, diffusion=diffusion, ddim_sample=ddim,
+                                      alphas_cumprod=dt.alphas_cumprod).numpy()
+            assert np.abs(x0 - g[f"x0_{j}_ddim"]).max() < 5e-4

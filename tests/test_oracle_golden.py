@@ -140,3 +140,21 @@ def test_whole_loop_matches_reference(golden, name, cfg, seed):
         k = torch.from_numpy(np.stack([ops["k_bic4"], ops["k_bic4"]]))[:, None]
     out = do.restore(sd, hp, cfg, y, k=k, mask=mask, noise_fn=seeded_noise_fn(seed))
     np.testing.assert_allclose(out.numpy(), g[name + "_out"], atol=2e-5)
+
+
+def test_model_fn_pred_xstart_ddim_flag_is_a_no_op(golden):
+    """Live-reference model_fn (utils_model.py:207-258): pred_xstart is identical for ddim_sample False / True and both
+    consume one randn_like; the oracle restatement reproduces it."""
+    import torch
+    g = golden("model_fn")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    dt, dtab = do.DriverTables(), do.DiffusionTables()
+    x = torch.from_numpy(g["x"])
+    for j, sig in enumerate(g["noise_levels"]):
+        assert np.array_equal(g[f"x0_{j}_ddim"], g[f"x0_{j}_psample"])
+        assert int(g[f"draws_{j}_ddim"]) == int(g[f"draws_{j}_psample"]) == 1
+        draws = []
+        x0 = do.model_fn_xstart(sd, hp, x, float(sig) * 255, dt, dtab, noise_fn=lambda t: draws.append(1)).numpy()
+        assert len(draws) == 1
+        assert np.abs(x0 - g[f"x0_{j}_psample"]).max() < 1e-5
