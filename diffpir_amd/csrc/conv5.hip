@@ -175,7 +175,7 @@ bool conv5_supported(int B, int Cout, int H, int W) {
     const long long px = (long long)B * H * W;
     if ((H * W) % 4) return false;
     // enough workgroups to occupy the chip; smaller problems stay on the split-K fp32 kernel
-    return ((px + 255) / 256) * ((Cout + 127) / 128) >= 96;
+    return ((px + 255) / 256) * ((Cout + 127) / 128) >= 32;
 }
 
 Status launch_conv5(hipStream_t s, const Conv5Args& a) {
