@@ -38,7 +38,8 @@ class LoopDesc(C.Structure):
                 ("y_dev", C.c_void_p), ("k_dev", C.c_void_p), ("mask_dev", C.c_void_p), ("labels_host", C.c_void_p),
                 ("noise_init_dev", C.c_void_p), ("noise_n1_dev", C.c_void_p), ("noise_n2_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("image_offset", C.c_int64), ("use_graph", C.c_int32),
-                ("skip_dead_final_eval", C.c_int32)]
+                ("skip_dead_final_eval", C.c_int32), ("generate_mode", C.c_int32), ("reserved0", C.c_int32),
+                ("noise_rp_dev", C.c_void_p)]
 
 
 PROF_CLASSES = 8
@@ -74,6 +75,7 @@ SIGNATURES = {
     "dpir_prox_ibp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dpir_bicubic_up": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dpir_renoise": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(Step), C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_repaint_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dpir_run_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.c_int, C.c_void_p, C.c_void_p]),

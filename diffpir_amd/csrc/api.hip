@@ -465,6 +465,12 @@ int dpir_renoise(dpir_engine* e, float* x, const float* x0, const dpir_step* s, 
     API_TRY(e, launch_renoise(e->stream, x, x0, coef_of(*s), s->es != 0.f ? n1 : nullptr, n2, (size_t)B * 3 * H * W));
     return DPIR_OK;
 }
+int dpir_repaint_mix(dpir_engine* e, float* x, const float* y, const uint8_t* mask, const dpir_step* s, const float* n, int B, int H, int W) {
+    if (!e || !x || !y || !mask || !s || !n) return fail(e, invalid("dpir_repaint_mix: null argument"));
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_repaint_mix(e->stream, x, y, mask, n, s->sa_t, s->s1m_t, (size_t)B * 3 * H * W));
+    return DPIR_OK;
+}
 int dpir_finalize(dpir_engine* e, const float* x, float* of, uint8_t* ou, int B, int H, int W) {
     if (!e || !x) return fail(e, invalid("dpir_finalize: null argument"));
     ProfScope ps(&e->prof, PC_ELEM);
@@ -516,6 +522,13 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
     hipStream_t s = e->stream;
     const int B = d.B, H = d.H, W = d.W;
     const size_t total = (size_t)B * 3 * H * W;
+    if (d.generate_mode == 1) {          // repaint: re-draw the known region at the current noise level (main_ddpir.py:355-358)
+        ProfScope ps(&e->prof, PC_ELEM);
+        const float* nr = d.noise_rp_dev;
+        size_t rstride = total;
+        if (!nr) { DPIR_TRY(launch_randn(s, b.n1, d.seed, 3, d.image_offset, B, (size_t)3 * H * W, b.cur)); nr = b.n1; rstride = 0; }
+        DPIR_TRY(launch_repaint_mix(s, b.x, d.y_dev, d.mask_dev, nr, 0.f, 0.f, total, b.cur, rstride));
+    }
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
     DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
     {
@@ -523,7 +536,9 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         DPIR_TRY(launch_xstart(s, b.x, b.out6, e->net.desc.out_channels, 0.f, 0.f, b.x0, B, H * W, b.cur));
     }
     if (last) return Status{};
-    if (d.task == DPIR_TASK_INPAINT) {
+    if (d.generate_mode != 0) {
+        // repaint / vanilla: no data-fidelity step (main_ddpir.py:385 is DiffPIR only)
+    } else if (d.task == DPIR_TASK_INPAINT) {
         ProfScope ps(&e->prof, PC_ELEM);
         DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, 0.f, d.guidance, total, b.cur));
     } else if (d.task == DPIR_TASK_SR_CUBIC) {
@@ -586,6 +601,9 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     if ((d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && !d.k_dev) return fail(e, invalid("dpir_run_loop: task needs a PSF"));
     if (d.task == DPIR_TASK_INPAINT && !d.mask_dev) return fail(e, invalid("dpir_run_loop: inpainting needs a mask"));
     if (d.task < 0 || d.task > 3) return fail(e, invalid("dpir_run_loop: unknown task"));
+    if (d.generate_mode < 0 || d.generate_mode > 2) return fail(e, invalid("dpir_run_loop: generate_mode must be 0 (DiffPIR), 1 (repaint) or 2 (vanilla)"));
+    if (d.generate_mode != 0 && d.task != DPIR_TASK_INPAINT)
+        return fail(e, invalid("dpir_run_loop: repaint / vanilla are inpainting modes (main_ddpir.py:448 re-noises only for inpainting or DiffPIR)"));
     if ((e->net.desc.num_classes > 0) != (d.labels_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
     const int B = d.B, H = d.H, W = d.W;
     const size_t total = (size_t)B * 3 * H * W;

@@ -18,6 +18,9 @@ Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_c
 Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp = nullptr);
 Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total,
                       const StepDev* sp = nullptr, size_t noise_step_stride = 0);
+// repaint conditioning before the denoiser call; sp != null: coefficients and the host-noise step offset come from the device step
+Status launch_repaint_mix(hipStream_t s, float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
+                          const StepDev* sp = nullptr, size_t noise_step_stride = 0);
 Status launch_init_x(hipStream_t s, const float* src, const uint8_t* mask, const float* noise, float sa, float s1m, float* x, size_t total);
 Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW);
 Status launch_affine(hipStream_t s, const float* x, float a, float b, float* out, size_t total);

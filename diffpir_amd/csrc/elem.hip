@@ -53,6 +53,24 @@ Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t*
     return Status{};
 }
 
+// ---------------------------------------------------------------- repaint conditioning (main_ddpir.py:355-358)
+// x = (sqrt_ac[t] * (2y - 1) + sqrt_1m_ac[t] * n) * mask + (1 - mask) * x      (generate_mode == 'repaint', inpainting)
+__global__ void repaint_mix_kernel(float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
+                                   const StepDev* sp, size_t stride) {
+    if (sp) { sa = sp->sa_t; s1m = sp->s1m_t; n += (size_t)sp->i * stride; }
+    GRID_STRIDE(i, total) {
+        float m = (float)mask[i];
+        float known = sa * (2.0f * y[i] - 1.0f) + s1m * n[i];
+        x[i] = known * m + (1.0f - m) * x[i];
+    }
+}
+Status launch_repaint_mix(hipStream_t s, float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
+                          const StepDev* sp, size_t noise_step_stride) {
+    hipLaunchKernelGGL(repaint_mix_kernel, grid1d(total), dim3(256), 0, s, x, y, mask, n, sa, s1m, total, sp, noise_step_stride);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
 // ---------------------------------------------------------------- re-noise
 __global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const float* n1, const float* n2, size_t total,
                                const StepDev* sp, size_t stride) {

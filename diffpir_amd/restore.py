@@ -69,10 +69,16 @@ class LoopConfig:
         # ddim_sample is accepted: with model_output_type=pred_xstart it selects the same x0 prediction and the same number
         # of RNG draws as p_sample (utils_model.py:219-240; tests/golden/model_fn.npz).  iter_num_U > 1 cannot be mirrored:
         # the reference raises IndexError on `seq[i+1]` at its last step (main_ddpir.py:448-451 with u < iter_num_U-1).
-        if self.generate_mode != "DiffPIR" or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
+        if self.generate_mode not in GENERATE_MODES or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
                 or self.iter_num_U != 1:
-            raise NotImplementedError("only generate_mode=DiffPIR, model_output_type=pred_xstart, sub_1_analytic=true, "
-                                      "iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
+            raise NotImplementedError("only generate_mode in (DiffPIR, repaint, vanilla), model_output_type=pred_xstart, "
+                                      "sub_1_analytic=true, iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
+        if self.generate_mode != "DiffPIR" and self.task != "inpaint":
+            # main_ddpir.py:448: outside DiffPIR mode x is only re-noised for inpainting; other tasks would leave x untouched
+            raise NotImplementedError("generate_mode repaint / vanilla are inpainting modes in the reference")
+
+
+GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2}
 
 
 def _steps(cfg: LoopConfig):
@@ -80,14 +86,18 @@ def _steps(cfg: LoopConfig):
                        skip_type=cfg.skip_type, T=cfg.num_train_timesteps, beta_start=cfg.beta_start, beta_end=cfg.beta_end)
 
 
-def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool):
-    """Consume noise_fn in the reference's order; keep only what the loop uses."""
+def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool, repaint: bool = False):
+    """Consume noise_fn in the reference's order; keep only what the loop uses.  Per step: [repaint mix], p_sample, then
+    (unless last) the eta draw and the zeta draw (main_ddpir.py:355-358, gaussian_diffusion.py:430, main_ddpir.py:454-456)."""
     init = np.asarray(noise_fn(shape), dtype=np.float32)
     n_re = sum(1 for s in steps if not s["last"])
     n1 = np.empty((n_re,) + tuple(shape), np.float32) if need_n1 else None
     n2 = np.empty((n_re,) + tuple(shape), np.float32)
+    nrp = np.empty((len(steps),) + tuple(shape), np.float32) if repaint else None
     j = 0
-    for s in steps:
+    for i, s in enumerate(steps):
+        if repaint:
+            nrp[i] = noise_fn(shape)
         noise_fn(shape)                                   # p_sample's randn_like (gaussian_diffusion.py:430), unused
         if not s["last"]:
             a = noise_fn(shape)
@@ -95,7 +105,7 @@ def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool):
                 n1[j] = a
             n2[j] = noise_fn(shape)
             j += 1
-    return init, n1, n2
+    return (init, n1, n2, nrp) if repaint else (init, n1, n2)
 
 
 def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=None, noise_source="device",
@@ -135,7 +145,13 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     if noise_source == "host":
         if noise_fn is None:
             raise EngineError("noise_source='host' needs noise_fn")
-        init, n1, n2 = draw_host_noise(noise_fn, steps, (B, 3, H, W), cfg.eta != 0)
+        rp = cfg.generate_mode == "repaint"
+        drawn = draw_host_noise(noise_fn, steps, (B, 3, H, W), cfg.eta != 0, repaint=rp)
+        init, n1, n2 = drawn[:3]
+        if rp:
+            drp = engine.to_device(drawn[3])
+            keep.append(drp)
+            d.noise_rp_dev = drp.ptr
         di, d2 = engine.to_device(init), engine.to_device(n2)
         keep += [di, d2]
         d.noise_init_dev, d.noise_n2_dev = di.ptr, d2.ptr
@@ -147,6 +163,7 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
         raise ValueError("noise_source must be 'host' or 'device'")
     d.seed, d.image_offset = seed, image_offset
     d.use_graph, d.skip_dead_final_eval = int(use_graph), int(skip_dead_final_eval)
+    d.generate_mode = GENERATE_MODES[cfg.generate_mode]
     if out_f32 is None:
         out_f32 = engine.empty((B, 3, H, W))
     if out_u8 is None and return_u8:
@@ -187,12 +204,17 @@ def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=No
     kwargs = {} if labels is None else {"y": labels}
     for i, st in enumerate(steps):
         curr_sigma = dt.reduced[st["t"]]
+        if cfg.generate_mode == "repaint":                  # main_ddpir.py:355-358
+            nr = eng.to_device(np.asarray(noise_fn(shape), np.float32))
+            eng._check(lib.dpir_repaint_mix(hnd, x.ptr, _ptr(y), _ptr(mask), C.byref(arr[i]), nr.ptr, B, H, W))
         x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type="pred_xstart", model_diffusion=model,
                                   diffusion=diffusion, ddim_sample=False, alphas_cumprod=dt.alphas_cumprod, **kwargs)
         noise_fn(shape)                                     # p_sample's draw
         if not st["last"]:
             tau = np.float32(st["tau"])
-            if cfg.task == "inpaint":
+            if cfg.generate_mode != "DiffPIR":
+                pass                                        # no data-fidelity step outside DiffPIR mode (main_ddpir.py:385)
+            elif cfg.task == "inpaint":
                 eng._check(lib.dpir_prox_mask(hnd, x0.ptr, _ptr(y), _ptr(mask), float(tau), cfg.guidance_scale, B, H, W))
             elif cfg.task == "deblur" or cfg.sr_mode == "blur":
                 x0_p = eng.empty(shape)

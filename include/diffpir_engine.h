@@ -160,6 +160,9 @@ int dpir_renoise(dpir_engine* e, float* x_dev, const float* x0_dev, const dpir_s
                  const float* n1_dev, const float* n2_dev, int B, int H, int W);
 /* Replaces main_ddpir.py:470,482 + utils_image.tensor2uint_batch (utils/utils_image.py:238-242):
  * x_dev [B,3,H,W] in [-1,1] -> out_f32 [B,3,H,W] = x/2+.5 (optional) and out_u8 [B,H,W,3] (optional). */
+/* main_ddpir.py:355-358: x = (sa_t*(2y-1) + s1m_t*n)*mask + (1-mask)*x  (coefficients from the step: sa_t, s1m_t) */
+int dpir_repaint_mix(dpir_engine* e, float* x_dev, const float* y_dev, const uint8_t* mask_dev, const dpir_step* s,
+                     const float* n_dev, int B, int H, int W);
 int dpir_finalize(dpir_engine* e, const float* x_dev, float* out_f32_dev, uint8_t* out_u8_dev, int B, int H, int W);
 /* N(0,1) on device (Philox4x32-10 + Box-Muller) keyed by (seed, image index offset, stream id):
  * the perf-mode replacement of torch.randn_like; parity mode feeds host noise. */
@@ -191,9 +194,15 @@ typedef struct dpir_loop_desc {
     int64_t image_offset;         /* global index of image 0 of this shard (multi-GPU invariance) */
     int32_t use_graph;            /* 1: capture one step as a hipGraph and replay it n_steps times */
     int32_t skip_dead_final_eval; /* 1: skip the last UNet call whose output is discarded (Q2) */
+    /* generate_mode (main_ddpir.py:349-358, 384): 0 DiffPIR (prox every step), 1 repaint (inpainting only: the known region
+     * is re-drawn at the current noise level before every denoiser call, no prox), 2 vanilla (inpainting only: no
+     * conditioning inside the loop).  Re-noising is applied in all three (main_ddpir.py:448). */
+    int32_t generate_mode;
+    int32_t reserved0;
+    const float* noise_rp_dev;    /* repaint, host-fed noise: [n_steps,B,3,H,W] in step order; NULL -> device Philox (draw 3) */
 } dpir_loop_desc;
 
-/* Runs init -> n_steps x (UNet -> prox -> re-noise) -> finalize.  Outputs (either may be NULL):
+/* Runs init -> n_steps x ([repaint mix ->] UNet -> [prox ->] re-noise) -> finalize.  Outputs (either may be NULL):
  * out_f32_dev [B,3,H,W] in [0,1] un-clamped (x_0 of main_ddpir.py:470), out_u8_dev [B,H,W,3]. */
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
                   float* out_f32_dev, uint8_t* out_u8_dev);

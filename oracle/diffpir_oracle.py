@@ -93,6 +93,7 @@ class LoopConfig:
     T: int = 1000
     beta_start: float = 0.0001
     beta_end: float = 0.02
+    generate_mode: str = "DiffPIR"       # DiffPIR | repaint | vanilla (the latter two: inpainting only)
 
     @property
     def sigma(self):                     # main_ddpir.py:141
@@ -296,11 +297,11 @@ def psnr_batch(a, b, max_pixel=2.0, eps=1e-10):
 
 def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = None, y_label=None,
             trace: Optional[list] = None, denoiser: Optional[Callable] = None):
-    """One batch of main_ddpir.py:259-470 (generate_mode='DiffPIR', pred_xstart, iter_num_U=1).
+    """One batch of main_ddpir.py:259-470 (generate_mode DiffPIR / repaint / vanilla, pred_xstart, iter_num_U=1).
 
     y [B,3,h,w] in [0,1]; k [B,1,kh,kw] (deblur/sr-blur); mask [B,3,H,W] float {0,1} (inpaint).
     noise_fn(like) -> N(0,1) tensor; called in the reference's draw order (SURVEY 8 a-R):
-    init, then per step: p_sample, n1 (eta term), n2 (zeta term).
+    init, then per step: [repaint mix], p_sample, n1 (eta term), n2 (zeta term).
     `denoiser(x, t_i) -> x0` overrides the UNet (used to test the loop without a network).
     Returns x_0 in [0,1] (un-clamped, main_ddpir.py:470)."""
     dt, steps = step_tables(cfg)
@@ -312,8 +313,12 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
     pre = None
     if cfg.task in ("sr", "deblur"):
         pre = pre_calculate(y, k.float(), cfg.sf)
+    if cfg.generate_mode != "DiffPIR" and cfg.task != "inpaint":
+        raise ValueError("repaint / vanilla: inpainting only (main_ddpir.py:448 re-noises only for inpainting or DiffPIR)")
     for st in steps:
         t_i = st["t_i"]
+        if cfg.generate_mode == "repaint":          # main_ddpir.py:355-358
+            x = (dt.sqrt_ac[t_i] * (2 * y - 1) + dt.sqrt_1m_ac[t_i] * noise_fn(x)) * mask + (1 - mask) * x
         if denoiser is not None:
             x0 = denoiser(x, t_i)
             noise_fn(x)
@@ -323,7 +328,9 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
             trace.append(("x0", t_i, x0.clone()))
         if not st["last"]:
             tau = st["tau"].repeat(1, 1, 1, 1)
-            if cfg.task == "inpaint":
+            if cfg.generate_mode != "DiffPIR":
+                pass                                # main_ddpir.py:385: the data-fidelity step is DiffPIR-only
+            elif cfg.task == "inpaint":
                 x0 = prox_mask(x0, y, mask, tau, cfg.guidance_scale)
             elif cfg.task == "deblur" or cfg.sr_mode == "blur":
                 x0 = prox_fft(x0, pre, tau, cfg.sf, cfg.guidance_scale)

@@ -51,7 +51,7 @@ def build_unet(hp, sd):
 
 
 def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_label=None, trace=None):
-    """main_ddpir.py:259-470 for generate_mode='DiffPIR', model_output_type='pred_xstart'."""
+    """main_ddpir.py:259-470 for generate_mode DiffPIR / repaint / vanilla, model_output_type='pred_xstart'."""
     ns = ref_import.load()
     utils_model, sr, Resizer = ns.utils_model, ns.utils_sisr, ns.utils_resizer.Resizer
     T = cfg.T
@@ -100,6 +100,10 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
         for i in range(len(seq)):
             curr_sigma = sigmas[seq[i]].cpu().numpy()
             t_i = utils_model.find_nearest(reduced_alpha_cumprod, curr_sigma)
+            gen_mode = getattr(cfg, "generate_mode", "DiffPIR")
+            if cfg.task == "inpaint" and gen_mode == 'repaint':            # main_ddpir.py:355-358
+                x = (sqrt_alphas_cumprod[t_i] * (2 * y - 1) + sqrt_1m_alphas_cumprod[t_i] * torch.randn_like(x)) * mask \
+                    + (1 - mask) * x
             x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_xstart',
                                       model_diffusion=model, diffusion=diffusion, ddim_sample=False,
                                       alphas_cumprod=alphas_cumprod, **model_kwargs)
@@ -107,7 +111,9 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
                 trace.append(("x0", int(t_i), x0.clone()))
             if seq[i] != seq[-1]:
                 tau = rhos[t_i].float().repeat(1, 1, 1, 1)
-                if cfg.task == "inpaint":
+                if gen_mode != 'DiffPIR':
+                    pass                                                   # main_ddpir.py:385: step 2 is DiffPIR-only
+                elif cfg.task == "inpaint":
                     x0_p = (mask * (2 * y - 1) + tau * x0).div(mask + tau)
                     x0 = x0 + cfg.guidance_scale * (x0_p - x0)
                 elif cfg.task == "deblur" or cfg.sr_mode == 'blur':

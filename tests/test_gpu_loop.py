@@ -124,3 +124,34 @@ def test_config_c1_full_size_psnr_parity(precision):
     # integer mask semantics: kept pixels follow the data term exactly as in the oracle
     assert np.abs(out - ref).max() < 5e-3
     engine.close()
+
+
+@pytest.mark.parametrize("mode", ["repaint", "vanilla"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_inpaint_generate_modes_match_live_reference_fixture(engine, tiny, golden, mode, graph):
+    """generate_mode repaint / vanilla (main_ddpir.py:349-358, 385, 448) through dpir_run_loop and through the stepwise plugs."""
+    g, gm = golden("loops"), golden("loops_modes")
+    cfg = restore.LoopConfig(task="inpaint", iter_num=6, noise_level_img=0.0, lambda_=1.0, zeta=1.0, generate_mode=mode)
+    seed = int(gm[f"inpaint_{mode}_seed"])
+    ref = gm[f"inpaint_{mode}_out"]
+    out = restore.restore_batch(engine, cfg, g["inpaint_y"], mask=g["inpaint_mask"], noise_source="host",
+                                noise_fn=seeded_noise_fn_np(seed), use_graph=graph).numpy()
+    assert np.abs(out - ref).max() < 2e-3
+    if not graph:
+        model, _ = tiny
+        from diffpir_amd import script_util
+        diffusion = script_util.create_gaussian_diffusion(steps=1000, learn_sigma=True)
+        eng = engine
+        sw = restore.restore_batch_stepwise(model, diffusion, cfg, eng.to_device(g["inpaint_y"]), mask=eng.to_device(g["inpaint_mask"], np.uint8),
+                                            noise_fn=seeded_noise_fn_np(seed)).numpy()
+        assert np.abs(sw - ref).max() < 2e-3
+        # device-noise path (Philox draw 3 for the repaint mix): runs, is finite and deterministic
+        a = restore.restore_batch(engine, cfg, g["inpaint_y"], mask=g["inpaint_mask"], noise_source="device", seed=7).numpy()
+        b = restore.restore_batch(engine, cfg, g["inpaint_y"], mask=g["inpaint_mask"], noise_source="device", seed=7, use_graph=True).numpy()
+        assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+def test_generate_modes_are_inpainting_only(engine, tiny, golden):
+    g = golden("loops")
+    with pytest.raises(NotImplementedError):
+        restore.restore_batch(engine, restore.LoopConfig(task="deblur", iter_num=3, generate_mode="repaint"), g["deblur_y"], k=g["deblur_k"])

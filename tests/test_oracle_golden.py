@@ -158,3 +158,20 @@ def test_model_fn_pred_xstart_ddim_flag_is_a_no_op(golden):
         x0 = do.model_fn_xstart(sd, hp, x, float(sig) * 255, dt, dtab, noise_fn=lambda t: draws.append(1)).numpy()
         assert len(draws) == 1
         assert np.abs(x0 - g[f"x0_{j}_psample"]).max() < 1e-5
+
+
+@pytest.mark.parametrize("mode", ["repaint", "vanilla"])
+def test_inpaint_generate_modes_match_live_reference(golden, mode):
+    """main_ddpir.py:349-358 (repaint conditioning before the denoiser), :385 (no prox outside DiffPIR mode), :448 (re-noise)."""
+    import torch
+    g, gm = golden("loops"), golden("loops_modes")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    cfg = do.LoopConfig(task="inpaint", iter_num=6, noise_level_img=0.0, lambda_=1.0, zeta=1.0, generate_mode=mode)
+    gen = torch.Generator().manual_seed(int(gm[f"inpaint_{mode}_seed"]))
+    nf = lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)
+    out = do.restore(sd, hp, cfg, torch.from_numpy(g["inpaint_y"]), mask=torch.from_numpy(g["inpaint_mask"]), noise_fn=nf).numpy()
+    assert np.abs(out - gm[f"inpaint_{mode}_out"]).max() < 2e-5
+    with pytest.raises(ValueError):
+        do.restore(sd, hp, do.LoopConfig(task="deblur", iter_num=3, generate_mode=mode), torch.from_numpy(g["deblur_y"]),
+                   k=torch.from_numpy(g["deblur_k"]), noise_fn=nf)
