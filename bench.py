@@ -223,7 +223,7 @@ def main():
                f"at {H}x{H} in {tcpu:.1f} s, extrapolated linearly to {args.nfe} NFE"}
 
     if rank == 0:
-        line = {"metric": "restored images/sec @100 NFE, 256x256", "value": round(value, 4), "unit": "images/s",
+        line = {"metric": f"restored images/sec @{args.nfe} NFE, {H}x{H}", "value": round(value, 4), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (GEMMs as 3 x f16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; exact-fp32-MFMA mode in alt_precision)",
