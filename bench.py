@@ -223,12 +223,15 @@ def main():
                f"at {H}x{H} in {tcpu:.1f} s, extrapolated linearly to {args.nfe} NFE"}
 
     if rank == 0:
+        cfg_tag = ("configs[1]" if (args.model, args.task, B, args.nfe, H) == ("ffhq", "deblur", 16, 100, 256) else
+                   "configs[2] topology/task (reduced batch or NFE)" if (args.model, args.task) == ("imagenet256", "sr") else
+                   "BASELINE configs[1] family, non-default flags")
         line = {"metric": f"restored images/sec @{args.nfe} NFE, {H}x{H}", "value": round(value, 4), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "f32" if args.precision == "f32" else "f32 (GEMMs as 3 x f16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; exact-fp32-MFMA mode in alt_precision)",
                 "data": "synthetic",
-                "config": {"workload": f"configs[1]: {args.model} topology {H}x{H} {args.task} "
+                "config": {"workload": f"{cfg_tag}: {args.model} topology {H}x{H} {args.task} "
                                        f"({'61x61 Gaussian PSF' if args.task == 'deblur' else args.task}), {args.nfe} NFE, "
                                        f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
                            "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results"},
