@@ -139,3 +139,50 @@ def test_yaml_driver_accepts_reference_style_configs(tmp_path):
             assert len(drv.sweeps(c)) == 11 and cfg.engine_task() == 1
         if c.task == "inpaint":
             assert cfg.engine_task() == 2 and cfg.iter_num == 20
+
+
+def test_host_noise_draw_order_with_repaint_matches_the_oracle_loop():
+    """restore.draw_host_noise must consume noise_fn exactly like the reference loop: init, then per step
+    [repaint mix], p_sample (dead), and unless last: eta draw, zeta draw (main_ddpir.py:315, 355-358, 448-456)."""
+    import torch
+    from diffpir_amd import restore
+    from oracle import diffpir_oracle as do, unet_oracle as uo
+    cfg = restore.LoopConfig(task="inpaint", iter_num=5, noise_level_img=0.0, lambda_=1.0, zeta=1.0, generate_mode="repaint")
+    _, steps, _ = restore._steps(cfg)
+    shape = (1, 3, 8, 8)
+    counter = {"n": 0}
+    def nf(shp):
+        counter["n"] += 1
+        return np.full(shp, counter["n"], np.float32)
+    init, n1, n2, nrp = restore.draw_host_noise(nf, steps, shape, need_n1=True, repaint=True)
+    # oracle: same loop with a stub denoiser, recording which draw index feeds which use
+    seen = []
+    ocount = {"n": 0}
+    def onf(like):
+        ocount["n"] += 1
+        seen.append(ocount["n"])
+        return torch.full(like.shape, float(ocount["n"]))
+    ocfg = do.LoopConfig(task="inpaint", iter_num=5, noise_level_img=0.0, lambda_=1.0, zeta=1.0, generate_mode="repaint")
+    y = torch.rand(shape); mask = (torch.rand(shape) > 0.5).float()
+    do.restore(None, uo.tiny_hp(), ocfg, y, mask=mask, noise_fn=onf, denoiser=lambda x, t: x * 0.5)
+    assert counter["n"] == ocount["n"]                       # same number of draws
+    assert init.flat[0] == 1
+    per = 4                                                  # repaint, p_sample, eta, zeta
+    for i, s in enumerate(steps):
+        assert nrp[i].flat[0] == 2 + per * i                 # the repaint draw is the first draw of every step
+        if not s["last"]:
+            assert n1[i].flat[0] == 2 + per * i + 2 and n2[i].flat[0] == 2 + per * i + 3
+    # without repaint the layout is the round-1 one
+    counter["n"] = 0
+    init, n1, n2 = restore.draw_host_noise(nf, steps, shape, need_n1=False)
+    assert n1 is None and n2[0].flat[0] == 4
+
+
+def test_generate_mode_validation():
+    from diffpir_amd import restore
+    restore.LoopConfig(task="inpaint", generate_mode="repaint").check_supported()
+    restore.LoopConfig(task="inpaint", generate_mode="vanilla", ddim_sample=True).check_supported()
+    for bad in (dict(task="deblur", generate_mode="repaint"), dict(task="inpaint", generate_mode="DPS_y0"),
+                dict(task="inpaint", iter_num_U=2), dict(task="deblur", model_output_type="pred_x_prev")):
+        with pytest.raises(NotImplementedError):
+            restore.LoopConfig(**bad).check_supported()
