@@ -31,6 +31,14 @@ def main():
         out[f"inpaint_{mode}_out"] = ref
         out[f"inpaint_{mode}_seed"] = np.array(seed)
         print(mode, "live-reference vs oracle max abs diff:", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()))
+    # skip_type: uniform (main_ddpir.py:328-331: seq = [i*skip] + [T-1]) on the DiffPIR inpainting loop, 5 + 1 steps
+    cfg = do.LoopConfig(task="inpaint", iter_num=5, noise_level_img=0.0, lambda_=1.0, zeta=1.0, skip_type="uniform")
+    with torch.no_grad():
+        ref = live_reference.restore_live(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(47)).numpy()
+        ora = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(47)).numpy()
+    out["inpaint_uniform_out"] = ref
+    out["inpaint_uniform_seed"] = np.array(47)
+    print("uniform live-reference vs oracle max abs diff:", float(np.abs(ref - ora).max()))
     np.savez_compressed(os.path.join(OUT, "loops_modes.npz"), **out)
 
 

@@ -186,3 +186,18 @@ def test_generate_mode_validation():
                 dict(task="inpaint", iter_num_U=2), dict(task="deblur", model_output_type="pred_x_prev")):
         with pytest.raises(NotImplementedError):
             restore.LoopConfig(**bad).check_supported()
+
+
+@pytest.mark.parametrize("skip_type,iter_num", [("uniform", 5), ("uniform", 10), ("quad", 7)])
+def test_engine_step_table_equals_oracle_step_table(skip_type, iter_num):
+    """The per-step scalars the engine uploads (schedule.build_steps) against the oracle's restatement of main_ddpir.py:274-347
+    (pinned to the live reference by the loop fixtures): same timesteps, same tau bits, same 'last' flag."""
+    _, steps, arr = schedule.build_steps(iter_num=iter_num, sigma=0.05, lambda_=7.0, zeta=0.3, skip_type=skip_type)
+    _, osteps = do.step_tables(do.LoopConfig(task="deblur", iter_num=iter_num, noise_level_img=0.05, lambda_=7.0, zeta=0.3,
+                                             skip_type=skip_type))
+    assert [s["t"] for s in steps] == [s["t_i"] for s in osteps]
+    assert [bool(s["last"]) for s in steps] == [bool(s["last"]) for s in osteps]
+    assert [s["t_im1"] for s in steps if not s["last"]] == [s["t_im1"] for s in osteps if not s["last"]]
+    np.testing.assert_array_equal(np.array([s["tau"] for s in steps], np.float32),
+                                  np.array([float(s["tau"]) for s in osteps], np.float32))
+    assert arr[len(steps) - 1].last == 1 and sum(a.last for a in arr) == 1

@@ -175,3 +175,16 @@ def test_inpaint_generate_modes_match_live_reference(golden, mode):
     with pytest.raises(ValueError):
         do.restore(sd, hp, do.LoopConfig(task="deblur", iter_num=3, generate_mode=mode), torch.from_numpy(g["deblur_y"]),
                    k=torch.from_numpy(g["deblur_k"]), noise_fn=nf)
+
+
+def test_uniform_skip_loop_matches_live_reference(golden):
+    """skip_type: uniform (main_ddpir.py:328-331) through the whole DiffPIR inpainting loop."""
+    import torch
+    g, gm = golden("loops"), golden("loops_modes")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    cfg = do.LoopConfig(task="inpaint", iter_num=5, noise_level_img=0.0, lambda_=1.0, zeta=1.0, skip_type="uniform")
+    gen = torch.Generator().manual_seed(int(gm["inpaint_uniform_seed"]))
+    nf = lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)
+    out = do.restore(sd, hp, cfg, torch.from_numpy(g["inpaint_y"]), mask=torch.from_numpy(g["inpaint_mask"]), noise_fn=nf).numpy()
+    assert np.abs(out - gm["inpaint_uniform_out"]).max() < 2e-5
