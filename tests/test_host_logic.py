@@ -201,3 +201,19 @@ def test_engine_step_table_equals_oracle_step_table(skip_type, iter_num):
     np.testing.assert_array_equal(np.array([s["tau"] for s in steps], np.float32),
                                   np.array([float(s["tau"]) for s in osteps], np.float32))
     assert arr[len(steps) - 1].last == 1 and sum(a.last for a in arr) == 1
+
+
+def test_load_checkpoint_reads_a_reference_style_state_dict(tmp_path):
+    """weights.load_checkpoint: torch.load of a guided-diffusion state dict (fp16 or fp32 tensors) -> fp32 numpy, reference keys kept."""
+    from diffpir_amd import weights
+    from oracle import unet_oracle as uo
+    sd = uo.synth_state_dict(uo.tiny_hp(), 3)
+    half = {k: (v.half() if i % 2 else v) for i, (k, v) in enumerate(sd.items())}      # checkpoints saved with use_fp16 hold f16 tensors
+    path = os.path.join(tmp_path, "tiny.pt")
+    torch.save(half, path)
+    got = weights.load_checkpoint(path)
+    assert list(got) == list(sd)
+    for i, (k, v) in enumerate(sd.items()):
+        assert got[k].dtype == np.float32
+        ref = v.half().float().numpy() if i % 2 else v.numpy()
+        np.testing.assert_array_equal(got[k], ref)
