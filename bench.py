@@ -74,14 +74,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     import torch
-    import torch.distributed as dist
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
-
     import diffpir_amd
-    from diffpir_amd import restore, synth, script_util, weights
+    from diffpir_amd import restore, synth, script_util, weights, dist as ddist
+    torch.cuda.set_device(local_rank)
+    ddist.init("nccl")          # RCCL over xGMI; a no-op at WORLD_SIZE == 1
+
     eng = diffpir_amd.Engine(local_rank)
     eng.set_precision(args.precision)
     B, H = args.batch, args.size
@@ -104,22 +101,21 @@ def main():
     mask = None if case["mask"] is None else eng.to_device(case["mask"])
     out_f32 = eng.empty((B, 3, H, H))
     out_u8 = torch.empty((B, H, H, 3), dtype=torch.uint8, device=f"cuda:{local_rank}")     # plumbing for RCCL
-    gathered = [torch.empty_like(out_u8) for _ in range(world)] if world > 1 else None
     keep = {}
 
     def one_step():
+        # weak scaling: every rank restores its own B images (global indices [rank*B, (rank+1)*B)), then the ONE collective of
+        # the path: all-gather of the uint8 results (diffpir_amd.dist, the same function the YAML driver uses)
         restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source="device", seed=1234, image_offset=rank * B,
                               use_graph=not args.no_graph, out_f32=out_f32, out_u8=out_u8, _cache=keep)
         eng.sync()
-        if world > 1:
-            dist.all_gather(gathered, out_u8)
+        ddist.all_gather_results(out_u8, B * world, rank, world)
 
     def fence():
         eng.sync()
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-            torch.cuda.synchronize()
+        ddist.barrier()
+        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         one_step()
@@ -129,10 +125,7 @@ def main():
         one_step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = ddist.max_over_ranks(elapsed, device=f"cuda:{local_rank}")
     images = B * world * args.steps
     value = images / elapsed
 
@@ -237,9 +230,7 @@ def main():
                            "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results"},
                 "roofline": roofline, "cpu_baseline": cpu, "alt_precision": alt}
         print(json.dumps(line))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    ddist.shutdown()
     eng.close()
 
 

@@ -82,6 +82,7 @@ SIGNATURES = {
     "dpir_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dpir_prof_reset": (C.c_int, [C.c_void_p]),
     "dpir_prof_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "dpir_graph_cache_size": (C.c_int, [C.c_void_p]),
     "dpir_unet_flops": (C.c_double, [C.c_void_p, C.c_int, C.c_int]),
     "dpir_unet_flops_class": (C.c_double, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
 }

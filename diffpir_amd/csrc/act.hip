@@ -16,14 +16,23 @@ __device__ __forceinline__ float silu_a(float v) {
     return v * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
+// f16 operand range guard.  The split clamps to +-65000 so that hi stays finite; a value that needed the clamp (or a NaN)
+// makes the result wrong, so it is COUNTED: one atomic per wave that saw one (none in the normal case), read back by
+// dpir_sync / dpir_d2h, which then fail with DPIR_ERR_RANGE instead of returning a silently saturated image.
+__device__ __forceinline__ void range_report(bool bad, unsigned long long* ctr) {
+    const unsigned long long m = __ballot(bad);
+    if (m != 0ull && ctr && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(m)) atomicAdd(ctr, (unsigned long long)__builtin_popcountll(m));
+}
+
 // grid: (ceil(H*W/256), B*C8); MODE 0 plain, 1 nearest-up (source is H/2 x W/2), 2 avg-pool (source is 2H x 2W)
 template <int MODE>
 __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4* prm, int C, int C8, int H, int W,
-                                                        _Float16* hi, _Float16* lo) {
+                                                        _Float16* hi, _Float16* lo, unsigned long long* range_ctr) {
     const int pix = blockIdx.x * 256 + threadIdx.x;
     const int n = blockIdx.y / C8, c8 = blockIdx.y - n * C8;
     const int HW = H * W;
     if (pix >= HW) return;
+    bool bad = false;
     const int y = pix / W, x = pix - y * W;
     const int Hs = MODE == 1 ? H >> 1 : (MODE == 2 ? H * 2 : H);
     const int Ws = MODE == 1 ? W >> 1 : (MODE == 2 ? W * 2 : W);
@@ -52,6 +61,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4
                 }
             }
         }
+        bad |= !(fabsf(v) <= 65000.f);
         v = fminf(fmaxf(v, -65000.f), 65000.f);
         _Float16 hh = (_Float16)v;
         h8[j] = hh;
@@ -60,10 +70,12 @@ __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4
     const size_t o = (((size_t)n * C8 + c8) * HW + pix) * 8;
     *reinterpret_cast<half8*>(hi + o) = h8;
     *reinterpret_cast<half8*>(lo + o) = l8;
+    range_report(bad, range_ctr);
 }
 
 // plain-resolution fast path: 4 consecutive pixels per thread (float4 loads per channel, 64-byte stores per plane)
-__global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float4* prm, int C, int C8, int HW, _Float16* hi, _Float16* lo) {
+__global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float4* prm, int C, int C8, int HW, _Float16* hi, _Float16* lo,
+                                                         unsigned long long* range_ctr) {
     const int p4 = blockIdx.x * 256 + threadIdx.x;          // group of 4 pixels
     const int n = blockIdx.y / C8, c8 = blockIdx.y - n * C8;
     const bool live = p4 * 4 < HW;
@@ -94,12 +106,14 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
     // instruction writes 1 KiB of consecutive entries.
     constexpr int PS = 256 + 4;                                 // plane stride in entries: conflict-free reads
     __shared__ half8 sh_hi[4 * PS], sh_lo[4 * PS];
+    bool bad = false;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         half8 h8, l8;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             float x = q == 0 ? v[j].x : (q == 1 ? v[j].y : (q == 2 ? v[j].z : v[j].w));
+            bad |= !(fabsf(x) <= 65000.f);
             x = fminf(fmaxf(x, -65000.f), 65000.f);
             _Float16 hh = (_Float16)x;
             h8[j] = hh;
@@ -108,6 +122,7 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
         sh_hi[q * PS + threadIdx.x] = h8;
         sh_lo[q * PS + threadIdx.x] = l8;
     }
+    range_report(bad, range_ctr);
     __syncthreads();
     const size_t o = ((size_t)n * C8 + c8) * HW + (size_t)blockIdx.x * 1024;      // first entry of this workgroup
     const int rem = HW - blockIdx.x * 1024;                                        // valid entries (multiple of 4)
@@ -124,17 +139,18 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
     }
 }
 
-Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo) {
+Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo,
+                        unsigned long long* range_ctr) {
     const int C = src.ca + src.cb, C8 = 2 * ((C + 15) / 16);   // whole 16-channel K chunks (zero padded)
     dim3 grid((unsigned)((H * W + 255) / 256), (unsigned)(B * C8));
     _Float16* h = reinterpret_cast<_Float16*>(hi);
     _Float16* l = reinterpret_cast<_Float16*>(lo);
     if (mode == 0 && (H * W) % 4 == 0) {
         dim3 g4((unsigned)((H * W / 4 + 255) / 256), (unsigned)(B * C8));
-        hipLaunchKernelGGL(act_split4_kernel, g4, dim3(256), 0, s, src, prm, C, C8, H * W, h, l);
-    } else if (mode == 0) hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l);
-    else if (mode == 1) hipLaunchKernelGGL(act_split_kernel<1>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l);
-    else hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l);
+        hipLaunchKernelGGL(act_split4_kernel, g4, dim3(256), 0, s, src, prm, C, C8, H * W, h, l, range_ctr);
+    } else if (mode == 0) hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);
+    else if (mode == 1) hipLaunchKernelGGL(act_split_kernel<1>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);
+    else hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

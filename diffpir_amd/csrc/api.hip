@@ -24,6 +24,21 @@ static int fail(dpir_engine* e, const Status& s) {
     } while (0)
 
 static void prox_release(dpir::ProxState* st);
+
+// f16x3 operand range guard: called where the ABI synchronises anyway (dpir_sync, D2H copies).  A non-zero count means
+// at least that many wave-lanes clamped an activation to the f16 range since the last check: the images are wrong.
+static int check_range(dpir_engine* e) {
+    if (!e->range_ctr || e->precision != 1) return DPIR_OK;
+    unsigned long long n = 0;
+    if (hipMemcpyAsync(&n, e->range_ctr, sizeof(n), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess)
+        return fail(e, Status{DPIR_ERR_HIP, "reading the operand range counter failed"});
+    if (n == 0) return DPIR_OK;
+    (void)hipMemsetAsync(e->range_ctr, 0, sizeof(n), e->stream);
+    return fail(e, Status{DPIR_ERR_RANGE, "f16x3 precision mode: " + std::to_string(n) + " activation lane(s) exceeded the f16 operand range "
+                                          "(|v| > 65000 or NaN) and were clamped -- results are invalid; rerun with precision f32 "
+                                          "(engine_precision: f32)"});
+}
 static int ilog2u(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 Status dpir_engine::fft_plan(int N, FftPlan* out) {
@@ -98,6 +113,8 @@ int dpir_create(int device, dpir_engine** out) {
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DPIR_ERR_HIP; }
     e->prof.stream = e->stream;
+    if (hipMalloc((void**)&e->range_ctr, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(e->range_ctr, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
     *out = e;
     return DPIR_OK;
 }
@@ -114,6 +131,7 @@ void dpir_destroy(dpir_engine* e) {
     for (void* p : e->user_allocs) (void)hipFree(p);
     e->invalidate_graphs();
     prox_release(&e->loop_prox);
+    if (e->range_ctr) (void)hipFree(e->range_ctr);
     (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -123,7 +141,7 @@ const char* dpir_last_error(const dpir_engine* e) { return e ? e->last_error.c_s
 int dpir_sync(dpir_engine* e) {
     if (!e) return DPIR_ERR_INVALID;
     API_HIP(e, hipStreamSynchronize(e->stream));
-    return DPIR_OK;
+    return check_range(e);
 }
 void* dpir_stream(dpir_engine* e) { return e ? (void*)e->stream : nullptr; }
 
@@ -157,7 +175,7 @@ int dpir_d2h(dpir_engine* e, void* h, const void* d, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;
     API_HIP(e, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
     API_HIP(e, hipStreamSynchronize(e->stream));
-    return DPIR_OK;
+    return check_range(e);
 }
 int dpir_d2d(dpir_engine* e, void* dd, const void* ds, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;
@@ -431,13 +449,13 @@ int dpir_resize_down(dpir_engine* e, const float* x, float* out, int sf, int B, 
 }
 
 static Status prox_ibp_impl(dpir_engine* e, float* x0, const float* y, float rho, float gamma, int in_iter, int sf, int B, int H, int W,
-                            const StepDev* sp = nullptr) {
+                            const StepDev* sp = nullptr, const LoopDev* lp = nullptr) {
     float* d = nullptr;
     DPIR_TRY(e->ws.getT("ibp#down", (size_t)B * 3 * (H / sf) * (W / sf), &d));
     for (int it = 0; it < in_iter; ++it) {
         DPIR_TRY(resize_down_impl(e, x0, 0.5f, 0.5f, d, sf, B, H, W));      // down(x0/2+.5)
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_ibp_update(e->stream, x0, y, d, gamma, rho, sf, B * 3, H, W, sp));
+        DPIR_TRY(launch_ibp_update(e->stream, x0, y, d, gamma, rho, sf, B * 3, H, W, sp, lp));
     }
     return Status{};
 }
@@ -488,7 +506,7 @@ int dpir_randn(dpir_engine* e, float* out, uint64_t seed, uint64_t stream_id, in
 
 // ------------------------------------------------------------------------------------------ whole loop
 namespace {
-struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; StepDev *steps_dev, *cur; };
+struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; StepDev *steps_dev, *cur; LoopDev* lp; };
 
 __global__ void fill_t_kernel(int* p, const StepDev* sp, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -526,8 +544,8 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         ProfScope ps(&e->prof, PC_ELEM);
         const float* nr = d.noise_rp_dev;
         size_t rstride = total;
-        if (!nr) { DPIR_TRY(launch_randn(s, b.n1, d.seed, 3, d.image_offset, B, (size_t)3 * H * W, b.cur)); nr = b.n1; rstride = 0; }
-        DPIR_TRY(launch_repaint_mix(s, b.x, d.y_dev, d.mask_dev, nr, 0.f, 0.f, total, b.cur, rstride));
+        if (!nr) { DPIR_TRY(launch_randn(s, b.n1, d.seed, 3, d.image_offset, B, (size_t)3 * H * W, b.cur, b.lp)); nr = b.n1; rstride = 0; }
+        DPIR_TRY(launch_repaint_mix(s, b.x, d.y_dev, d.mask_dev, nr, 0.f, 0.f, total, b.cur, rstride, b.lp));
     }
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
     DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
@@ -540,9 +558,9 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         // repaint / vanilla: no data-fidelity step (main_ddpir.py:385 is DiffPIR only)
     } else if (d.task == DPIR_TASK_INPAINT) {
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, 0.f, d.guidance, total, b.cur));
+        DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, 0.f, d.guidance, total, b.cur, b.lp));
     } else if (d.task == DPIR_TASK_SR_CUBIC) {
-        DPIR_TRY(prox_ibp_impl(e, b.x0, d.y_dev, 0.f, d.gamma, d.in_iter, d.sf, B, H, W, b.cur));
+        DPIR_TRY(prox_ibp_impl(e, b.x0, d.y_dev, 0.f, d.gamma, d.in_iter, d.sf, B, H, W, b.cur, b.lp));
     } else {
         DPIR_TRY(data_solution_impl(e, *prox, b.x0, 0.5f, 0.5f, 1.f, b.x0, 2.f, -1.f, b.x0, d.guidance, b.cur));
     }
@@ -551,20 +569,14 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
     ProfScope ps(&e->prof, PC_ELEM);
     if (with_n1) {
         if (d.noise_n1_dev) n1 = d.noise_n1_dev;
-        else { DPIR_TRY(launch_randn(s, b.n1, d.seed, 1, d.image_offset, B, (size_t)3 * H * W, b.cur)); n1 = b.n1; }
+        else { DPIR_TRY(launch_randn(s, b.n1, d.seed, 1, d.image_offset, B, (size_t)3 * H * W, b.cur, b.lp)); n1 = b.n1; }
     }
     if (d.noise_n2_dev) { n2 = d.noise_n2_dev; stride = total; }
-    else { DPIR_TRY(launch_randn(s, b.n2, d.seed, 2, d.image_offset, B, (size_t)3 * H * W, b.cur)); n2 = b.n2; }
+    else { DPIR_TRY(launch_randn(s, b.n2, d.seed, 2, d.image_offset, B, (size_t)3 * H * W, b.cur, b.lp)); n2 = b.n2; }
     if (with_n1 && d.noise_n1_dev && !d.noise_n2_dev) return invalid("host n1 noise requires host n2 noise");
-    DPIR_TRY(launch_renoise(s, b.x, b.x0, RenoiseCoef{}, n1, n2, total, b.cur, stride));
+    DPIR_TRY(launch_renoise(s, b.x, b.x0, RenoiseCoef{}, n1, n2, total, b.cur, stride, b.lp));
     DPIR_HIP(hipGetLastError());
     return Status{};
-}
-
-uint64_t fnv(uint64_t h, const void* p, size_t n) {
-    const unsigned char* c = reinterpret_cast<const unsigned char*>(p);
-    for (size_t i = 0; i < n; ++i) { h ^= c[i]; h *= 1099511628211ull; }
-    return h;
 }
 
 Status capture_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, ProxState* prox, bool last, bool with_n1,
@@ -617,18 +629,19 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     API_TRY(e, e->ws.getT("loop#t", (size_t)B, &b.t_dev));
     API_TRY(e, e->ws.getT("loop#steps", (size_t)n_steps, &b.steps_dev));
     API_TRY(e, e->ws.getT("loop#cur", (size_t)1, &b.cur));
+    API_TRY(e, e->ws.getT("loop#lp", (size_t)1, &b.lp));
     API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
     bool need_prox = d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR;
     ProxState& prox = e->loop_prox;
-    if (need_prox && (prox.B != B || prox.H != H || prox.W != W || !prox.FB)) {
+    // sf decides the spectrum layout (half-spectrum register FFT vs bit-reversed c2c): a change of sf re-allocates too
+    if (need_prox && (prox.B != B || prox.H != H || prox.W != W || prox.sf != d.sf || prox.half != fft2_supported(H, W, d.sf) || !prox.FB)) {
         API_HIP(e, hipStreamSynchronize(e->stream));
         prox_release(&prox);
         e->invalidate_graphs();
         API_TRY(e, prox_alloc(d.sf, B, H, W, &prox));
     }
-    prox.sf = d.sf;
 
-    // per-step scalar table -> device (one small H2D per batch)
+    // per-step scalar table and the per-batch device block -> device (two small H2D copies per batch)
     bool with_n1 = false;
     {
         std::vector<StepDev> hs(n_steps);
@@ -636,9 +649,13 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
             const dpir_step& st = steps[i];
             hs[i] = StepDev{st.t, st.last, i, 0, st.c1, st.c2, st.tau, st.sa_t, st.s1m_t, st.sa_p, st.k1, st.q, st.es, st.k2};
             if (!st.last && st.es != 0.f) with_n1 = true;
-            if (st.last && i != n_steps - 1) return fail(e, invalid("dpir_run_loop: only the final step may be marked last"));
+            // the reference marks EVERY step with seq[i] == seq[-1] as final (two of them for quad skipping with
+            // iter_num > T/2): each is a dead denoiser call, prox and re-noise are skipped (main_ddpir.py:384, 448)
+            if (i > 0 && steps[i - 1].last && !st.last) return fail(e, invalid("dpir_run_loop: a non-final step may not follow a final step"));
         }
+        LoopDev hl{d.y_dev, d.mask_dev, d.noise_n1_dev, d.noise_n2_dev, d.noise_rp_dev, (unsigned long long)d.seed, (long long)d.image_offset};
         API_HIP(e, hipMemcpyAsync(b.steps_dev, hs.data(), sizeof(StepDev) * n_steps, hipMemcpyHostToDevice, e->stream));
+        API_HIP(e, hipMemcpyAsync(b.lp, &hl, sizeof(hl), hipMemcpyHostToDevice, e->stream));
         API_HIP(e, hipStreamSynchronize(e->stream));
     }
     if (with_n1 && d.noise_n2_dev && !d.noise_n1_dev) return fail(e, invalid("dpir_run_loop: eta != 0 with host noise needs noise_n1_dev"));
@@ -655,31 +672,42 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
         }
         hipGraphExec_t& g = last ? g_last : g_step;
         if (!g) {
-            // one graph per (descriptor, workspace generation, step kind); the descriptor holds every pointer baked in
-            uint64_t key = fnv(1469598103934665603ull, &d, sizeof(d));
-            key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
-            int kind = (last ? 1 : 0) | (with_n1 ? 2 : 0);
-            key = fnv(key, &kind, sizeof(kind));
-            auto it = e->graphs.find(key);
-            if (it == e->graphs.end()) {
+            auto make_key = [&]() {
+                dpir_engine::GraphKey k{};
+                k.task = d.task; k.B = B; k.H = H; k.W = W; k.sf = d.sf; k.in_iter = d.in_iter; k.generate_mode = d.generate_mode;
+                k.kind = (last ? 1 : 0) | (with_n1 ? 2 : 0);
+                k.host_n1 = d.noise_n1_dev != nullptr; k.host_n2 = d.noise_n2_dev != nullptr; k.host_rp = d.noise_rp_dev != nullptr;
+                k.has_labels = d.labels_host != nullptr;
+                k.gamma = d.gamma; k.guidance = d.guidance; k.ws_generation = e->ws.generation;
+                return k;
+            };
+            auto find = [&](const dpir_engine::GraphKey& k) -> dpir_engine::GraphEntry* {
+                for (auto& ge : e->graphs) if (memcmp(&ge.key, &k, sizeof(k)) == 0) return &ge;
+                return nullptr;
+            };
+            dpir_engine::GraphEntry* hit = find(make_key());
+            if (!hit) {
                 // warm-up: run this step eagerly once so that every workspace buffer exists before capture
                 // (it is a real step of the loop: its result is kept and the graph is used from the next one)
-                uint64_t gen0 = e->ws.generation;
                 API_TRY(e, loop_step(e, d, b, &prox, last, with_n1));
-                if (e->ws.generation != gen0) {   // buffers were created: keys must use the settled generation
-                    key = fnv(1469598103934665603ull, &d, sizeof(d));
-                    key = fnv(key, &e->ws.generation, sizeof(e->ws.generation));
-                    key = fnv(key, &kind, sizeof(kind));
-                }
                 API_HIP(e, hipStreamSynchronize(e->stream));
                 hipGraphExec_t exec = nullptr;
                 API_TRY(e, capture_step(e, d, b, &prox, last, with_n1, &exec));
-                dpir_engine::GraphEntry ge; ge.exec = exec;
-                e->graphs[key] = ge;
+                if (e->graphs.size() >= dpir_engine::kMaxGraphs) {        // evict the least recently used graph
+                    size_t lru = 0;
+                    for (size_t q = 1; q < e->graphs.size(); ++q) if (e->graphs[q].last_use < e->graphs[lru].last_use) lru = q;
+                    // never the partner graph of this very loop
+                    if (e->graphs[lru].exec == g_step || e->graphs[lru].exec == g_last) lru = (lru + 1) % e->graphs.size();
+                    (void)hipGraphExecDestroy(e->graphs[lru].exec);
+                    e->graphs.erase(e->graphs.begin() + lru);
+                }
+                dpir_engine::GraphEntry ge; ge.key = make_key(); ge.exec = exec; ge.last_use = ++e->graph_clock;   // key: the settled generation
+                e->graphs.push_back(ge);
                 g = exec;
                 continue;   // this step was executed eagerly
             }
-            g = it->second.exec;
+            hit->last_use = ++e->graph_clock;
+            g = hit->exec;
         }
         ProfScope ps(&e->prof, PC_LOOP);
         API_HIP(e, hipGraphLaunch(g, e->stream));
@@ -715,32 +743,34 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
     a.src.a = x; a.src.ca = Cin; a.src.Hs = Hs; a.src.Ws = Ws; a.src.mode = mode; a.src.prm = with_prm ? prm : nullptr;
     a.w = w; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.CoutP = coutp; a.H = H; a.W = W; a.ks = ks;
     a.partial = partial; a.partial_capacity = (size_t)16 * 1024 * 1024; a.dbg = dbg & ~64;
+    const void* w16 = nullptr; float w16_scale = 1.f;
     if (dbg & 64) {   // operand-split f16 path with synthetic split weights
         std::vector<float> hw((size_t)Cout * Cin * taps);
         for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
-        std::vector<uint16_t> w16;
-        a.w16_scale = (ks == 1 && (dbg & 128)) ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16) : pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16);
+        std::vector<uint16_t> w16h;
+        std::vector<uint16_t>& w16v = w16h;
+        w16_scale = ks == 1 ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16v) : pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16v);
         void* wp = nullptr;
-        API_TRY(e, e->ws.get("dbg#w16", w16.size() * 2, &wp));
-        API_HIP(e, hipMemcpy(wp, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
-        a.w16 = wp;
+        API_TRY(e, e->ws.get("dbg#w16", w16v.size() * 2, &wp));
+        API_HIP(e, hipMemcpy(wp, w16v.data(), w16v.size() * 2, hipMemcpyHostToDevice));
+        w16 = wp;
     }
     Conv4Args a4;
     Conv5Args a5;
     const bool use5 = (dbg & 128) != 0 && ks == 1;
     if (use5) {
-        a5.src = CatSrc{x, Cin, nullptr, 0}; a5.prm = a.src.prm; a5.w16 = a.w16; a5.w16_scale = a.w16_scale; a5.bias = bias; a5.out = out;
+        a5.src = CatSrc{x, Cin, nullptr, 0}; a5.prm = a.src.prm; a5.w16 = w16; a5.w16_scale = w16_scale; a5.bias = bias; a5.out = out;
         a5.B = B; a5.Cout = Cout; a5.H = H; a5.W = W;
     }
     bool use4 = (dbg & 128) != 0 && ks == 3;
     if (use4) {
-        if (!a.w16) return fail(e, invalid("debug bench: conv4 needs dbg bit 64 (split weights) as well"));
+        if (!w16) return fail(e, invalid("debug bench: conv4 needs dbg bit 64 (split weights) as well"));
         int C8 = 2 * ((Cin + 15) / 16);
         size_t plane = (size_t)B * C8 * H * W * 16;
         char* s16 = nullptr;
         API_TRY(e, e->ws.getT("dbg#s16", 2 * plane, &s16));
         if (!(dbg & 256)) API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, s16, s16 + plane));
-        a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = a.w16; a4.w16_scale = a.w16_scale; a4.bias = bias; a4.out = out;
+        a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = w16; a4.w16_scale = w16_scale; a4.bias = bias; a4.out = out;
         a4.B = B; a4.Cin = Cin; a4.Cout = Cout; a4.H = H; a4.W = W; a4.partial = partial; a4.partial_capacity = a.partial_capacity;
         a4.dbg = (dbg & 31) | (dbg & (1024 | 2048));
     }
@@ -764,6 +794,7 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
 }
 
 // ------------------------------------------------------------------------------------------ profiling
+int dpir_graph_cache_size(dpir_engine* e) { return e ? (int)e->graphs.size() : 0; }
 int dpir_prof_enable(dpir_engine* e, int on) {
     if (!e) return DPIR_ERR_INVALID;
     e->prof.collect();

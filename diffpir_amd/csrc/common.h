@@ -107,8 +107,6 @@ struct ConvArgs {
     float* partial = nullptr;     // split-K slab (optional) and its capacity in floats
     size_t partial_capacity = 0;
     int dbg = 0;                  // ablation bits (debug bench only)
-    const void* w16 = nullptr;    // operand-split f16 weights (conv3.hip layout) or null -> exact fp32 kernels
-    float w16_scale = 1.f;        // power-of-two pre-scale of w16
 };
 Status launch_conv(hipStream_t s, const ConvArgs& a);
 float pack_weights_f16x3(const float* w_oihw, int cout, int cin, int ks, std::vector<uint16_t>& out);
@@ -119,7 +117,9 @@ struct CatSrc { const float* a; int ca; const float* b; int cb; };
 
 // act.hip + conv4.hip: operand-split f16 path with a separate activation pre-pass
 // hi / lo: blocked [B][C8][H][W][8] f16 planes, C8 = 2*ceil(C/16); mode: 0 plain, 1 nearest-up source, 2 avg-pool source
-Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo);
+// range_ctr: device counter of operand values outside the f16 range (see act.hip range_report), or null
+Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo,
+                        unsigned long long* range_ctr = nullptr);
 struct Conv4Args {
     const void* xhi = nullptr; const void* xlo = nullptr;   // split activations (Cin channels, output resolution)
     const void* w16 = nullptr; float w16_scale = 1.f;
@@ -137,6 +137,7 @@ struct Conv5Args {
     const void* w16 = nullptr; float w16_scale = 1.f;
     const float* bias = nullptr; float* out = nullptr; const float* res = nullptr;   // res: same shape as out, or null
     int B = 0, Cout = 0, H = 0, W = 0;
+    unsigned long long* range_ctr = nullptr;   // f16 operand range guard (act.hip range_report)
 };
 bool conv5_supported(int B, int Cout, int H, int W);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);

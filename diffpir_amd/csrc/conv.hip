@@ -414,7 +414,6 @@ static Status launch_cfg(hipStream_t s, ConvK k) {
 }
 
 Status launch_conv2(hipStream_t s, const ConvArgs& a);
-Status launch_conv3(hipStream_t s, const ConvArgs& a);
 
 Status launch_conv(hipStream_t s, const ConvArgs& a) {
     if (a.ks != 1 && a.ks != 3) return invalid("conv: ks must be 1 or 3");
@@ -434,15 +433,6 @@ Status launch_conv(hipStream_t s, const ConvArgs& a) {
     if (eh != a.src.Hs || ew != a.src.Ws) return invalid("conv: source resolution does not match mode");
     if (a.src.mode == 1 && ((a.H | a.W) & 1)) return invalid("conv: up mode needs even output size");
     // generation-2 kernel (conv2.hip) for plain / up-sampled sources; the pooled-source variant stays on v1
-    // operand-split f16 path (conv3.hip) when the layer carries split weights; falls back for shapes it does not tile
-    if (a.w16 && a.ks == 3 && a.src.mode != 2 && !(a.dbg & 32)) {   // 1x1 convs are staging-bound: they stay on conv2
-        int KCs = a.ks == 3 ? 16 : 32;
-        bool aligned = a.src.cb == 0 || (a.src.ca % KCs) == 0;
-        if (aligned && a.W >= 8) {
-            Status s3 = launch_conv3(s, a);
-            if (s3.code != DPIR_ERR_UNSUPPORTED) return s3;   // shapes conv3 does not tile fall through to the fp32 kernels
-        }
-    }
     if (a.src.mode != 2 && !(a.dbg & 32) && a.CoutP % 64 == 0) return launch_conv2(s, a);
     // pixel tile: TW x TH x TI = 128
     int tw = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : (a.W >= 8 ? 8 : 4));

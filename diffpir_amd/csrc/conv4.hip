@@ -1,5 +1,14 @@
-// conv4: 3x3 implicit-GEMM convolution on the f16 matrix pipe with operand splitting (see conv3.hip for the
-// arithmetic and its measured accuracy), fed ONLY by LDS-DMA: the activation operand has already been normalised,
+// conv4: 3x3 implicit-GEMM convolution on the f16 matrix pipe with OPERAND SPLITTING: every fp32 operand is split into
+// two f16 halves (x = hi + lo, hi = f16(x), lo = f16(x - hi)) and each product is evaluated as
+//     lo_w*hi_x + hi_w*lo_x + hi_w*hi_x                (3 x v_mfma_f32_32x32x16_f16, fp32 accumulate, small terms first)
+// i.e. a 22-bit-mantissa product; the dropped lo*lo term is 2^-22 relative.  Measured on this chip
+// (tools/micro/mfma_f16x3_probe.hip): max error of a K=16 dot product 2.7e-7 vs 4.5e-7 for the exact-fp32 MFMA chain,
+// f16 subnormal inputs are NOT flushed, operand mapping A[i][8g+j] / B[8g+j][i'] for lane (i = l%32, g = l/32), element j.
+// Weights are pre-scaled by a per-layer power of two (exactly undone in the epilogue) so that their low halves stay normal.
+// Why: fp32 MFMA runs on the vector ALU (157 TF/s peak), f16 MFMA has its own pipe at 2.5 PF/s: 3 MFMAs per product =
+// 833 TF/s fp32-equivalent.
+//
+// The kernel is fed ONLY by LDS-DMA: the activation operand has already been normalised,
 // activated, resampled, concatenated and split into f16 hi/lo halves by act.hip, in the blocked layout
 // [n][C/8][H][W][8] whose 16-byte entries are exactly one lane's MFMA B-operand fragment.  The kernel contains no
 // staging arithmetic at all: per K chunk of 16 input channels a workgroup issues
@@ -8,11 +17,20 @@
 // Tile: 64 output channels x 512 pixels (16 x 32 patch), 8 waves x (64 x 64): two waves per SIMD, weight traffic per
 // MFMA half of the 256-pixel tile's.  LDS: 2 x 36 KiB weights + 2 x 2 x 21 KiB activations = 156 KiB, one workgroup per CU.
 #include "common.h"
+#include <math.h>
+#include <vector>
 
 namespace dpir {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+// Ablation switches (tools/conv_ablation.py) exist only in -DDPIR_ABLATE builds; the product kernel has none of them.
+#ifdef DPIR_ABLATE
+#define ABL(bit) ((p.dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
 
 #ifndef DMA_SLOTS_PER_TAP
 #define DMA_SLOTS_PER_TAP 2
@@ -128,14 +146,14 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     // taps of the previous chunk (two per tap), so the vector-memory queue never fills and stalls the MFMA issue.
     constexpr int NSLOT = NWT + 2 * NXT;
     auto issue_slot = [&](int chunk, int buf, int slot) {
-        if (p.dbg & 4) return;
+        if (ABL(4)) return;
         if (slot < NWT) {
-            if (p.dbg & 1024) return;
+            if (ABL(1024)) return;
             int piece = wave + slot * 8;
             const char* wsrc = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * WBYTES + lane * 16;
             if (piece < WPIECES) GLDS4(wsrc + piece * 1024, lds_w + buf * WBYTES + piece * 1024);
         } else {
-            if (p.dbg & 2048) return;
+            if (ABL(2048)) return;
             const int u = (slot - NWT) >> 1, plane = (slot - NWT) & 1;
             int piece = wave + u * 8;
             if (piece < XPIECES) {
@@ -176,13 +194,13 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
         }
     };
     __syncthreads();                        // chunk ch_begin has landed (vmcnt(0) precedes the barrier)
-    if (!(p.dbg & 1)) load_step(0, 0, 0);
+    if (!ABL(1)) load_step(0, 0, 0);
     int it = 0;
     for (int chunk = ch_begin; chunk < ch_end; ++chunk, ++it) {
         const int cur = it & 1;
         const bool more = chunk + 1 < ch_end;
 
-        if (p.dbg & 1) {                    // ablation: DMA only
+        if (ABL(1)) {                       // ablation: DMA only
             if (more) {
 #pragma unroll
                 for (int sl = 0; sl < NSLOT; ++sl) issue_slot(chunk + 1, cur ^ 1, sl);
@@ -239,7 +257,7 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
     // ---- epilogue.  Vector path (W % 4 == 0): each wave transposes its 64co x 64px accumulators through its own 17 KiB
     // LDS slab so that every lane owns 4 consecutive pixels of one channel: float4 residual loads and float4 NCHW stores
     // (4 channel rows x 256 B per instruction) instead of 64 scalar stores per lane.
-    if ((p.W & 3) == 0 && !(p.dbg & 16)) {
+    if ((p.W & 3) == 0 && !ABL(16)) {
         constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
         // Same-resolution residual: all 16 float4 loads of this lane are requested up front, so their latency is paid
         // once (and overlaps the transpose) instead of once per unrolled batch of the store loop.
@@ -340,7 +358,7 @@ __global__ __launch_bounds__(512, 2) void conv4_mfma_kernel(Conv4K p) {
         int ti = pp >> (p.ltw + p.lth);
         int n = n0 + ti, y = ty0 + py, x = tx0 + px;
         bool pok = ti < TI && n < p.B && y < p.H && x < p.W;
-        if (p.dbg & 16) {
+        if (ABL(16)) {
 #pragma unroll
             for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -477,6 +495,39 @@ Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written) {
     }
     DPIR_HIP(hipGetLastError());
     return Status{};
+}
+
+
+// Host: OIHW fp32 -> [chunk][co-block][hi|lo][tap][k-half (2KB)][64 co][8] f16, scaled by a power of two so that
+// max|w|*scale is in [512, 1024).  Returns the scale.
+float pack_weights_f16x3(const float* w, int cout, int cin, int ks, std::vector<uint16_t>& out) {
+    const int taps = ks * ks, KB = 1, KC = 16;   // ks == 3 (the 1x1 layout is pack_weights_f16x3_1x1, conv5.hip)
+    const int chunks = (cin + KC - 1) / KC, cblocks = (cout + 63) / 64;
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * taps; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    float scale = 1.0f;
+    if (mx > 0.f) scale = exp2f(floorf(log2f(1024.0f / mx)) - 0.0f);
+    while (mx * scale >= 1024.0f) scale *= 0.5f;
+    const size_t plane = (size_t)taps * 2 * KB * 64 * 8;
+    out.assign((size_t)chunks * cblocks * 2 * plane, 0);
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int cbk = 0; cbk < cblocks; ++cbk) {
+            uint16_t* hi = out.data() + ((size_t)ch * cblocks + cbk) * 2 * plane;
+            uint16_t* lo = hi + plane;
+            for (int tap = 0; tap < taps; ++tap)
+                for (int kh = 0; kh < 2 * KB; ++kh)
+                    for (int col = 0; col < 64; ++col)
+                        for (int j = 0; j < 8; ++j) {
+                            int co = cbk * 64 + col, ci = ch * KC + kh * 8 + j;
+                            float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] * scale : 0.f;
+                            _Float16 h = (_Float16)v;
+                            _Float16 l = (_Float16)(v - (float)h);
+                            size_t o = (((size_t)tap * 2 * KB + kh) * 64 + col) * 8 + j;
+                            __builtin_memcpy(&hi[o], &h, 2);
+                            __builtin_memcpy(&lo[o], &l, 2);
+                        }
+        }
+    return scale;
 }
 
 }  // namespace dpir

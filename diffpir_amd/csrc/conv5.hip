@@ -22,6 +22,7 @@ struct Conv5K {
     long long total_px;
     const float* zeros;
     float out_scale;
+    unsigned long long* range_ctr;
 };
 
 #define GLDS5(src, dst) \
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    bool bad = false;
     issue_dma(0, 0);
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
         const int cur = chunk & 1;
@@ -119,6 +121,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
             }
 #pragma unroll
             for (int jj = 0; jj < 8; ++jj) {
+                bad |= !(fabsf(v[jj]) <= 65000.f);
                 float x = fminf(fmaxf(v[jj], -65000.f), 65000.f);
                 _Float16 hh = (_Float16)x;
                 bh[j][jj] = hh;
@@ -145,6 +148,10 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], acc[i][j], 0, 0, 0);
     }
 
+    {   // f16 operand range guard: see act.hip range_report
+        const unsigned long long m = __ballot(bad);
+        if (m != 0ull && p.range_ctr && lane == __builtin_ctzll(m)) atomicAdd(p.range_ctr, (unsigned long long)__builtin_popcountll(m));
+    }
     // ---- epilogue: un-scale, bias (+ residual), 128-byte coalesced NCHW stores
     const int co0 = co_blk * 128;
 #pragma unroll
@@ -190,6 +197,7 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a) {
     k.zeros = conv_zero_page();
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv5: cannot allocate the zero page"};
     k.out_scale = 1.0f / a.w16_scale;
+    k.range_ctr = a.range_ctr;
     const unsigned blocks = (unsigned)(((k.total_px + 255) / 256) * k.n_co_blocks);
     if (a.prm) hipLaunchKernelGGL(conv5_mfma_kernel<true>, dim3(blocks), dim3(256), 0, s, k);
     else hipLaunchKernelGGL(conv5_mfma_kernel<false>, dim3(blocks), dim3(256), 0, s, k);

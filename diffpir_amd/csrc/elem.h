@@ -14,23 +14,33 @@ struct StepDev {
     float c1, c2, tau, sa_t, s1m_t, sa_p, k1, q, es, k2;
 };
 
+// Per-batch values of dpir_run_loop that kernels read on the device (fixed address): with them out of the kernel
+// arguments, ONE captured step graph serves every batch of the same shape (new y / mask / noise pointers, seed and
+// image offset only rewrite this 64-byte block).
+struct LoopDev {
+    const float* y; const uint8_t* mask;
+    const float* n1; const float* n2; const float* nrp;     // host-fed noise tensors (parity mode) or null
+    unsigned long long seed; long long image_offset;
+};
+
 Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_ch, float c1, float c2, float* x0, int B, int HW, const StepDev* sp = nullptr);
-Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp = nullptr);
+Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp = nullptr,
+                        const LoopDev* lp = nullptr);
 Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total,
-                      const StepDev* sp = nullptr, size_t noise_step_stride = 0);
+                      const StepDev* sp = nullptr, size_t noise_step_stride = 0, const LoopDev* lp = nullptr);
 // repaint conditioning before the denoiser call; sp != null: coefficients and the host-noise step offset come from the device step
 Status launch_repaint_mix(hipStream_t s, float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
-                          const StepDev* sp = nullptr, size_t noise_step_stride = 0);
+                          const StepDev* sp = nullptr, size_t noise_step_stride = 0, const LoopDev* lp = nullptr);
 Status launch_init_x(hipStream_t s, const float* src, const uint8_t* mask, const float* noise, float sa, float s1m, float* x, size_t total);
 Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW);
 Status launch_affine(hipStream_t s, const float* x, float a, float b, float* out, size_t total);
 Status launch_band_resample(hipStream_t s, const float* in, const float* w, const int* idx, int taps, int P, int L_in,
                             int L_out, int inner, float pa, float pb, float* out);
 Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W,
-                         const StepDev* sp = nullptr);
+                         const StepDev* sp = nullptr, const LoopDev* lp = nullptr);
 Status launch_bicubic_up(hipStream_t s, const float* in, float* out, int P, int h, int w, int sf);
 Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image,
-                    const StepDev* sp = nullptr);   // sp: stream_id += 2 * sp->i
+                    const StepDev* sp = nullptr, const LoopDev* lp = nullptr);   // sp: stream_id += 4 * sp->i; lp: seed / image_offset from the device block
 void resizer_band(int in_len, int out_len, double scale, std::vector<float>& w_out, std::vector<int>& idx_out, int& taps_out);
 
 // fft.hip ------------------------------------------------------------------------------------

@@ -37,8 +37,10 @@ Status launch_xstart(hipStream_t s, const float* x, const float* out6, int out_c
 }
 
 // ---------------------------------------------------------------- masked prox
-__global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp) {
+__global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp,
+                                 const LoopDev* lp) {
     if (sp) tau = sp->tau;
+    if (lp) { y = lp->y; mask = lp->mask; }
     GRID_STRIDE(i, total) {
         float m = (float)mask[i];
         float v = x0[i];
@@ -47,8 +49,9 @@ __global__ void prox_mask_kernel(float* x0, const float* y, const uint8_t* mask,
         x0[i] = v + g * (xp - v);
     }
 }
-Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp) {
-    hipLaunchKernelGGL(prox_mask_kernel, grid1d(total), dim3(256), 0, s, x0, y, mask, tau, g, total, sp);
+Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t* mask, float tau, float g, size_t total, const StepDev* sp,
+                        const LoopDev* lp) {
+    hipLaunchKernelGGL(prox_mask_kernel, grid1d(total), dim3(256), 0, s, x0, y, mask, tau, g, total, sp, lp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -56,7 +59,8 @@ Status launch_prox_mask(hipStream_t s, float* x0, const float* y, const uint8_t*
 // ---------------------------------------------------------------- repaint conditioning (main_ddpir.py:355-358)
 // x = (sqrt_ac[t] * (2y - 1) + sqrt_1m_ac[t] * n) * mask + (1 - mask) * x      (generate_mode == 'repaint', inpainting)
 __global__ void repaint_mix_kernel(float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
-                                   const StepDev* sp, size_t stride) {
+                                   const StepDev* sp, size_t stride, const LoopDev* lp) {
+    if (lp) { y = lp->y; mask = lp->mask; if (stride) n = lp->nrp; }
     if (sp) { sa = sp->sa_t; s1m = sp->s1m_t; n += (size_t)sp->i * stride; }
     GRID_STRIDE(i, total) {
         float m = (float)mask[i];
@@ -65,15 +69,16 @@ __global__ void repaint_mix_kernel(float* x, const float* y, const uint8_t* mask
     }
 }
 Status launch_repaint_mix(hipStream_t s, float* x, const float* y, const uint8_t* mask, const float* n, float sa, float s1m, size_t total,
-                          const StepDev* sp, size_t noise_step_stride) {
-    hipLaunchKernelGGL(repaint_mix_kernel, grid1d(total), dim3(256), 0, s, x, y, mask, n, sa, s1m, total, sp, noise_step_stride);
+                          const StepDev* sp, size_t noise_step_stride, const LoopDev* lp) {
+    hipLaunchKernelGGL(repaint_mix_kernel, grid1d(total), dim3(256), 0, s, x, y, mask, n, sa, s1m, total, sp, noise_step_stride, lp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 
 // ---------------------------------------------------------------- re-noise
 __global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const float* n1, const float* n2, size_t total,
-                               const StepDev* sp, size_t stride) {
+                               const StepDev* sp, size_t stride, const LoopDev* lp) {
+    if (lp && stride) { if (n1) n1 = lp->n1; n2 = lp->n2; }     // host-fed noise: this batch's tensors
     if (sp) {
         c.sa_t = sp->sa_t; c.s1m_t = sp->s1m_t; c.sa_p = sp->sa_p; c.k1 = sp->k1; c.q = sp->q; c.es = sp->es; c.k2 = sp->k2;
         if (n1) n1 += (size_t)sp->i * stride;
@@ -90,8 +95,8 @@ __global__ void renoise_kernel(float* x, const float* x0, RenoiseCoef c, const f
     }
 }
 Status launch_renoise(hipStream_t s, float* x, const float* x0, const RenoiseCoef& c, const float* n1, const float* n2, size_t total,
-                      const StepDev* sp, size_t noise_step_stride) {
-    hipLaunchKernelGGL(renoise_kernel, grid1d(total), dim3(256), 0, s, x, x0, c, n1, n2, total, sp, noise_step_stride);
+                      const StepDev* sp, size_t noise_step_stride, const LoopDev* lp) {
+    hipLaunchKernelGGL(renoise_kernel, grid1d(total), dim3(256), 0, s, x, x0, c, n1, n2, total, sp, noise_step_stride, lp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -169,8 +174,9 @@ Status launch_band_resample(hipStream_t s, const float* in, const float* w, cons
 
 // IBP update: x0 <- 2*( z + gamma*(y - d)[up nearest]/(1+rho) ) - 1, z = x0/2+.5   (main_ddpir.py:404-406)
 __global__ void ibp_update_kernel(float* x0, const float* y, const float* d, float gamma, float rho, int sf, int H, int W, size_t total,
-                                  const StepDev* sp) {
+                                  const StepDev* sp, const LoopDev* lp) {
     if (sp) rho = sp->tau;
+    if (lp) y = lp->y;
     GRID_STRIDE(i, total) {
         size_t plane = i / ((size_t)H * W);
         size_t r = i - plane * (size_t)H * W;
@@ -184,9 +190,9 @@ __global__ void ibp_update_kernel(float* x0, const float* y, const float* d, flo
     }
 }
 Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* d, float gamma, float rho, int sf, int P, int H, int W,
-                         const StepDev* sp) {
+                         const StepDev* sp, const LoopDev* lp) {
     size_t total = (size_t)P * H * W;
-    hipLaunchKernelGGL(ibp_update_kernel, grid1d(total), dim3(256), 0, s, x0, y, d, gamma, rho, sf, H, W, total, sp);
+    hipLaunchKernelGGL(ibp_update_kernel, grid1d(total), dim3(256), 0, s, x0, y, d, gamma, rho, sf, H, W, total, sp, lp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -248,8 +254,10 @@ __device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5
 
 // one thread produces 4 normals for elements [4j, 4j+4) of image (image_offset + n); counter = (j, image, stream)
 __global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, size_t per_image, size_t total4,
-                             const StepDev* sp) {
-    if (sp) stream_id += 2 * (uint64_t)sp->i;
+                             const StepDev* sp, const LoopDev* lp) {
+    // draw kinds per step: 1 = eta term, 2 = zeta term, 3 = repaint mix -> a stride of 4 keeps every (kind, step) pair distinct
+    if (sp) stream_id += 4 * (uint64_t)sp->i;
+    if (lp) { seed = lp->seed; image_offset = lp->image_offset; }
     GRID_STRIDE(i, total4) {
         size_t q = (per_image + 3) / 4;
         size_t n = i / q, j = i - n * q;
@@ -272,9 +280,9 @@ __global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int6
     }
 }
 Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image,
-                    const StepDev* sp) {
+                    const StepDev* sp, const LoopDev* lp) {
     size_t total4 = (size_t)B * ((per_image + 3) / 4);
-    hipLaunchKernelGGL(randn_kernel, grid1d(total4), dim3(256), 0, s, out, seed, stream_id, image_offset, per_image, total4, sp);
+    hipLaunchKernelGGL(randn_kernel, grid1d(total4), dim3(256), 0, s, out, seed, stream_id, image_offset, per_image, total4, sp, lp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -85,13 +85,26 @@ struct dpir_engine {
     std::vector<void*> user_allocs;
     bool collect_taps = true;
     int precision = 0;           // 0: exact fp32 MFMA kernels; 1: operand-split f16x3 MFMA (fp32-equivalent accuracy)
-    struct GraphEntry { hipGraphExec_t exec = nullptr; };
-    std::map<uint64_t, GraphEntry> graphs;       // captured restoration loops, keyed by descriptor content
+    // Captured restoration steps.  A graph depends only on what is baked into its kernel arguments: the shape / task /
+    // mode fields below and the workspace generation; per-batch pointers, seed and image offset live in a device block
+    // (dpir::LoopDev), so every batch of a test set replays the same graph.  Entries are compared field by field on a
+    // hit (no hash-only match) and the cache is capped (least recently used entry is destroyed).
+    struct GraphKey {
+        int32_t task, B, H, W, sf, in_iter, generate_mode, kind;      // kind: bit0 final step, bit1 eta draw
+        int32_t host_n1, host_n2, host_rp, has_labels;
+        float gamma, guidance;
+        uint64_t ws_generation;
+    };
+    struct GraphEntry { GraphKey key; hipGraphExec_t exec = nullptr; uint64_t last_use = 0; };
+    std::vector<GraphEntry> graphs;
+    uint64_t graph_clock = 0;
+    static constexpr size_t kMaxGraphs = 16;
     dpir::ProxState loop_prox;                   // spectra owned by dpir_run_loop
     void invalidate_graphs() {
-        for (auto& g : graphs) if (g.second.exec) (void)hipGraphExecDestroy(g.second.exec);
+        for (auto& g : graphs) if (g.exec) (void)hipGraphExecDestroy(g.exec);
         graphs.clear();
     }
+    unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);
     dpir::Status fft2_table(int N, const float2** out);

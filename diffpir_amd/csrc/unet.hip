@@ -289,7 +289,7 @@ struct Fwd {
             DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
             {
                 ProfScope ps(&e->prof, PC_ELEM);
-                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane));
+                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane, e->range_ctr));
             }
             Conv4Args a4;
             a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = cw.w16; a4.w16_scale = cw.w16_scale;
@@ -310,6 +310,7 @@ struct Fwd {
             Conv5Args a5;
             a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
             a5.bias = cw.bias; a5.out = out; a5.res = res; a5.B = B; a5.Cout = cw.cout; a5.H = Ho; a5.W = Wo;
+            a5.range_ctr = e->range_ctr;
             fused.erase(out);
             ProfScope ps(&e->prof, PC_CONV1);
             return launch_conv5(s, a5);
@@ -321,7 +322,6 @@ struct Fwd {
         a.w = cw.w; a.bias = cw.bias; a.out = out; a.res = res; a.res_mode = res_mode;
         a.B = B; a.Cin = cw.cin; a.Cout = cw.cout; a.CoutP = cw.coutp; a.H = Ho; a.W = Wo; a.ks = cw.ks;
         a.partial = partial; a.partial_capacity = partial_cap;
-        a.w16 = cw.w16; a.w16_scale = cw.w16_scale;
         ProfScope ps(&e->prof, cw.ks == 3 ? PC_CONV3 : PC_CONV1);
         return launch_conv(s, a);
     }

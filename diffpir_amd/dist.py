@@ -23,13 +23,40 @@ def shard_range(n_images: int, rank: int, world: int) -> Tuple[int, int]:
 
 
 def init(backend: str = "nccl"):
+    """One process per GPU (launched by torch.distributed.run): joins the process group when WORLD_SIZE > 1.
+    backend "nccl" is RCCL over xGMI on ROCm; "gloo" (host staging) is what the single-GPU / CPU tests use."""
     import torch.distributed as dist
     rank, local_rank, world = env_rank_world()
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         dist.init_process_group(backend, rank=rank, world_size=world)
     return rank, local_rank, world
+
+
+def barrier():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+
+
+def max_over_ranks(value: float, device=None) -> float:
+    """MAX all-reduce of one scalar (the bench's elapsed time)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
+def shutdown():
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def all_gather_results(local, n_images: int, rank: int, world: int):
@@ -44,6 +71,44 @@ def all_gather_results(local, n_images: int, rank: int, world: int):
     pad = local
     if local.shape[0] < mx:
         pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], 0)
+    pad = pad.contiguous()
+    if dist.get_backend() == "gloo" and pad.is_cuda:       # gloo stages through the host (tests on one GPU)
+        pad = pad.cpu()
     bufs = [torch.empty_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad.contiguous())
-    return torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+    dist.all_gather(bufs, pad)
+    out = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+    return out.to(local.device)
+
+
+def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int, world: int, image_offset: int = 0, seed: int = 0,
+                    use_graph: bool = True, noise_source: str = "device", host_noise=None, cache: dict = None,
+                    skip_dead_final_eval: bool = False):
+    """One GLOBAL batch restored by `world` ranks: rank r runs images [lo, hi) of the batch on its own GPU (its own engine,
+    its own replayed graph, no collective inside the loop) and ONE all-gather of the uint8 results ends the batch
+    (SURVEY.md 8e).  y / k / mask / labels are the global batch (numpy, host); every rank slices its block.
+
+    Device noise is keyed by the global image index (image_offset + lo + b), so the gathered result is independent of
+    `world`.  Host noise (parity mode) must be pre-drawn for the GLOBAL batch: host_noise = (init, n1, n2[, nrp]) as returned
+    by restore.draw_host_noise for the global shape; each rank uploads its image slice.
+    Returns (uint8 [n_images, H, W, 3] on every rank as a torch tensor on this rank's device, local fp32 DeviceArray)."""
+    import numpy as np
+    import torch
+    from . import restore
+    n = y.shape[0]
+    lo, hi = shard_range(n, rank, world)
+    sl = slice(lo, hi)
+    H, W = y.shape[2] * cfg.sf, y.shape[3] * cfg.sf
+    out_u8 = torch.empty((hi - lo, H, W, 3), dtype=torch.uint8, device=f"cuda:{engine.device}")
+    if hi > lo:
+        kw = dict(k=None if k is None else np.ascontiguousarray(k[sl]), mask=None if mask is None else np.ascontiguousarray(mask[sl]),
+                  labels=None if labels is None else np.asarray(labels)[sl], seed=seed, image_offset=image_offset + lo,
+                  use_graph=use_graph, out_u8=out_u8, _cache=cache, skip_dead_final_eval=skip_dead_final_eval)
+        if noise_source == "host":
+            drawn = [None if a is None else (np.ascontiguousarray(a[sl]) if a.ndim == 4 else np.ascontiguousarray(a[:, sl])) for a in host_noise]
+            out_f32 = restore.restore_batch(engine, cfg, np.ascontiguousarray(y[sl]), noise_source="host", predrawn=drawn, **kw)
+        else:
+            out_f32 = restore.restore_batch(engine, cfg, np.ascontiguousarray(y[sl]), noise_source="device", **kw)
+        engine.sync()
+    else:
+        out_f32 = None
+    return all_gather_results(out_u8, n, rank, world), out_f32

@@ -17,6 +17,11 @@ class EngineError(RuntimeError):
     pass
 
 
+class EngineRangeError(EngineError):
+    """DPIR_ERR_RANGE: in f16x3 mode an activation left the f16 operand range and was clamped -- the images are wrong.
+    Reload the model on an engine with set_precision('f32') (YAML: engine_precision: f32)."""
+
+
 def _ptr(a) -> Optional[int]:
     """Raw device address of a DeviceArray / torch cuda tensor / int / None."""
     if a is None:
@@ -102,7 +107,8 @@ class Engine:
     def _check(self, rc: int):
         if rc != 0:
             msg = self.lib.dpir_last_error(self.h)
-            raise EngineError(f"engine error {rc}: {msg.decode() if msg else ''}")
+            cls = EngineRangeError if rc == -6 else EngineError
+            raise cls(f"engine error {rc}: {msg.decode() if msg else ''}")
 
     # ---- memory
     def empty(self, shape, dtype=np.float32) -> DeviceArray:
@@ -171,6 +177,9 @@ class Engine:
 
     def unet_flops(self, H, W, cls: int = -1) -> float:
         return float(self.lib.dpir_unet_flops_class(self.h, H, W, cls))
+
+    def graph_cache_size(self) -> int:
+        return int(self.lib.dpir_graph_cache_size(self.h))
 
     # ---- profiling
     def prof_enable(self, on=True):

@@ -1,6 +1,9 @@
 """YAML-driven batched driver with the reference's config surface (main_ddpir.py:127-169, 172-599), on the engine.
 
-    python -m diffpir_amd.main_ddpir --opt <config.yaml> [--synthetic N] [--device 0]
+    python -m diffpir_amd.main_ddpir --opt <config.yaml> [--synthetic N] [--device 0] [--num-gpus G]
+
+--num-gpus G (or the YAML key `num_gpus`) re-launches the driver as G processes, one per GPU (torch.distributed.run); every batch
+is then block-partitioned over the ranks (dist.restore_sharded) and one all-gather of the uint8 results ends it.
 
 Accepts the reference's configs/*.yaml unchanged.  What it keeps from the reference driver: the derived fields
 (noise_level_img/255, sigma = max(0.001, .), kernel_std), the per-task lambda/zeta sweeps (main_ddpir.py:548-580),
@@ -60,7 +63,9 @@ def loop_config(config, lambda_, zeta) -> restore.LoopConfig:
                               skip_type=config.skip_type, num_train_timesteps=config.num_train_timesteps,
                               beta_start=config.beta_start, beta_end=config.beta_end, generate_mode=config.generate_mode,
                               model_output_type=config.model_output_type, sub_1_analytic=config.sub_1_analytic,
-                              ddim_sample=config.ddim_sample, iter_num_U=config.iter_num_U)
+                              ddim_sample=config.ddim_sample, iter_num_U=config.iter_num_U,
+                              noise_init_img=config.get("noise_init_img", "max"),
+                              skip_noise_model_t=bool(config.get("skip_noise_model_t", False)))
 
 
 def sweeps(config):
@@ -121,17 +126,37 @@ def degrade(config, gt, idx0):
     return y, k, mask
 
 
+def psnr_per_image(a: np.ndarray, b: np.ndarray, max_pixel=2.0, eps=1e-10) -> np.ndarray:
+    """Per-image terms of utils_image.calculate_psnr_batch (utils/utils_image.py:601-610); their mean is the batch PSNR."""
+    mse = np.mean((a.astype(np.float32) - b.astype(np.float32)) ** 2, axis=(1, 2, 3), dtype=np.float32)
+    with np.errstate(divide="ignore"):
+        v = np.where(mse == 0, np.inf, 20 * np.log10(max_pixel / np.sqrt(mse + np.float32(eps))))
+    return np.where(np.isnan(v), 0.0, v)
+
+
 def main(argv=None):
+    import sys
     ap = argparse.ArgumentParser()
     ap.add_argument("--opt", type=str, required=True, help="Path to option YAML file.")
     ap.add_argument("--synthetic", type=int, default=0, help="use N synthetic images instead of the testset")
-    ap.add_argument("--device", type=int, default=0)
+    ap.add_argument("--device", type=int, default=None, help="HIP ordinal (default: LOCAL_RANK, else 0)")
     ap.add_argument("--max-sweeps", type=int, default=0)
+    ap.add_argument("--num-gpus", type=int, default=0, help="shard every batch over this many GPUs (one process per GPU)")
+    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the result all-gather (nccl = RCCL)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
     config = parse_config(args.opt)
+    num_gpus = args.num_gpus or int(config.get("num_gpus", 1) or 1)
+    if num_gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # one process per GPU: re-launch under torch.distributed.run (rendezvous on 127.0.0.1)
+        import subprocess
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={num_gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", os.environ.get("MASTER_PORT", "29541"), "-m", "diffpir_amd.main_ddpir"] + list(argv if argv is not None else sys.argv[1:])
+        return subprocess.call(cmd)
+    from . import dist as ddist
+    rank, local_rank, world = ddist.init(args.dist_backend)
     np.random.seed(config.seed)
-    eng = Engine(args.device)
+    eng = Engine(args.device if args.device is not None else local_rank)
     eng.set_precision(str(config.get("engine_precision", "f16x3")))      # before load_state_dict: selects the weight packing
 
     model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
@@ -151,32 +176,49 @@ def main(argv=None):
     imgs, names = load_images(config, args.synthetic)
     use_graph = bool(config.get("engine_graph", True))
     noise = config.get("engine_noise", "device")
+    host_gen = None
+    if noise == "host":
+        # ONE generator for the whole run, like the reference's global torch RNG (main_ddpir.py:131): successive batches
+        # continue the stream instead of replaying it
+        import torch
+        host_gen = torch.Generator().manual_seed(config.seed)
     results = []
+    cache = {}
     for si, (lambda_, zeta) in enumerate(sweeps(config)):
         if args.max_sweeps and si >= args.max_sweeps:
             break
         cfg = loop_config(config, lambda_, zeta)
-        log.info("eta:%s, zeta:%s, lambda:%s, guidance_scale:%s", config.eta, zeta, lambda_, config.guidance_scale)
+        if rank == 0:
+            log.info("eta:%s, zeta:%s, lambda:%s, guidance_scale:%s", config.eta, zeta, lambda_, config.guidance_scale)
         psnrs, t0, n = [], time.time(), 0
         for i0 in range(0, len(imgs), config.batch_size):
             gt = imgs[i0:i0 + config.batch_size]
-            y, k, mask = degrade(config, gt, i0)
-            nf = None
+            y, k, mask = degrade(config, gt, i0)                     # every rank synthesises the same global batch (seeded numpy)
+            drawn = None
             if noise == "host":
                 import torch
-                g = torch.Generator().manual_seed(config.seed)
-                nf = lambda shape: torch.randn(tuple(shape), generator=g).numpy()
-            out = restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source=noise, noise_fn=nf, seed=config.seed,
-                                        image_offset=i0, use_graph=use_graph,
-                                        skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False))).numpy()
-            p = restore.psnr_batch(out * 2 - 1, gt * 2 - 1)
+                _, steps, _ = restore._steps(cfg)
+                nf = lambda shape: torch.randn(tuple(shape), generator=host_gen).numpy()
+                drawn = restore.draw_host_noise(nf, steps, (len(gt), 3, gt.shape[2], gt.shape[3]), cfg.eta != 0,
+                                                repaint=cfg.generate_mode == "repaint")
+            u8, out_f32 = ddist.restore_sharded(eng, cfg, y, k=k, mask=mask, rank=rank, world=world, image_offset=i0, seed=config.seed,
+                                                use_graph=use_graph, noise_source=noise, host_noise=drawn, cache=cache,
+                                                skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False)))
+            lo, hi = ddist.shard_range(len(gt), rank, world)
+            import torch
+            local = psnr_per_image(out_f32.numpy() * 2 - 1, gt[lo:hi] * 2 - 1) if hi > lo else np.zeros(0)
+            per_img = ddist.all_gather_results(torch.from_numpy(np.asarray(local, np.float64)), len(gt), rank, world).numpy()
+            p = float(np.mean(per_img))
             psnrs.append(p * len(gt))
             n += len(gt)
-            log.info("batch%4d--> PSNR: %.4fdB", i0 // config.batch_size + 1, p)
+            if rank == 0:
+                log.info("batch%4d--> PSNR: %.4fdB", i0 // config.batch_size + 1, p)
         dt = time.time() - t0
-        log.info("-----------> Average PSNR(RGB) of (%s) scale factor: (%d), sigma: (%.3f): %.4f dB  [%.2f images/s]",
-                 config.testset_name, config.sf, config.noise_level_model, sum(psnrs) / n, n / dt)
+        if rank == 0:
+            log.info("-----------> Average PSNR(RGB) of (%s) scale factor: (%d), sigma: (%.3f): %.4f dB  [%.2f images/s on %d GPU(s)]",
+                     config.testset_name, config.sf, config.noise_level_model, sum(psnrs) / n, n / dt, world)
         results.append(sum(psnrs) / n)
+    ddist.shutdown()
     eng.close()
     return results
 

@@ -23,7 +23,7 @@ import numpy as np
 
 from . import _lib
 from .engine import Engine, DeviceArray, _ptr, EngineError
-from .schedule import build_steps
+from .schedule import build_steps, find_nearest
 
 TASKS = {"deblur": 0, "sr_blur": 1, "inpaint": 2, "sr_cubic": 3}
 
@@ -51,6 +51,8 @@ class LoopConfig:
     sub_1_analytic: bool = True
     ddim_sample: bool = False
     iter_num_U: int = 1
+    noise_init_img: object = "max"      # 'max' -> t_start = T-1, else a noise level in /255 units (main_ddpir.py:197-200)
+    skip_noise_model_t: bool = False    # main_ddpir.py:192-195, 391
 
     @property
     def sigma(self):
@@ -81,9 +83,29 @@ class LoopConfig:
 GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2}
 
 
+def t_start_of(cfg: LoopConfig, reduced) -> int:
+    """main_ddpir.py:197-200: the timestep the forward-noised initial image is placed at; steps above it are skipped (:346)."""
+    if cfg.noise_init_img == "max":
+        return cfg.num_train_timesteps - 1
+    return find_nearest(reduced, 2 * float(cfg.noise_init_img) / 255)
+
+
 def _steps(cfg: LoopConfig):
+    T = cfg.num_train_timesteps
+    t_start = None
+    if cfg.noise_init_img != "max" or cfg.skip_noise_model_t:
+        from .schedule import DriverTables
+        red = DriverTables.make(cfg.beta_start, cfg.beta_end, T).reduced
+        t_start = t_start_of(cfg, red)
+        if cfg.skip_noise_model_t:
+            # main_ddpir.py:391 compares the LOOP INDEX with T - noise_model_t; the branch it guards (a switch to pred_x_prev that
+            # persists for the rest of the run, :407-413) is dead for every iter_num below that bound -- and not mirrored beyond it
+            noise_model_t = find_nearest(red, 2 * cfg.noise_level_img)
+            if cfg.iter_num > T - noise_model_t:
+                raise NotImplementedError("skip_noise_model_t with iter_num > T - noise_model_t selects the reference's pred_x_prev "
+                                          "fallback (main_ddpir.py:407-413), which is not on the accelerated path")
     return build_steps(iter_num=cfg.iter_num, sigma=cfg.sigma, lambda_=cfg.lambda_, zeta=cfg.zeta, eta=cfg.eta,
-                       skip_type=cfg.skip_type, T=cfg.num_train_timesteps, beta_start=cfg.beta_start, beta_end=cfg.beta_end)
+                       skip_type=cfg.skip_type, T=T, beta_start=cfg.beta_start, beta_end=cfg.beta_end, t_start=t_start)
 
 
 def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool, repaint: bool = False):
@@ -110,7 +132,8 @@ def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool, repaint: bo
 
 def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=None, noise_source="device",
                   noise_fn: Optional[Callable] = None, seed: int = 0, image_offset: int = 0, use_graph: bool = False,
-                  skip_dead_final_eval: bool = False, out_f32=None, out_u8=None, return_u8: bool = False, _cache: dict = None):
+                  skip_dead_final_eval: bool = False, out_f32=None, out_u8=None, return_u8: bool = False, _cache: dict = None,
+                  predrawn=None):
     """y: [B,3,h,w] in [0,1]; k: [B,1,kh,kw]; mask: uint8 [B,3,H,W] -- device arrays (or numpy, uploaded).
     Returns a DeviceArray [B,3,H,W] = x_0 in [0,1] (un-clamped, main_ddpir.py:470), and the u8 NHWC
     array as well when return_u8."""
@@ -135,7 +158,7 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     if k is not None:
         d.kh, d.kw = k.shape[2], k.shape[3]
     d.in_iter, d.gamma, d.guidance = cfg.inIter, cfg.gamma, cfg.guidance_scale
-    t_start = cfg.num_train_timesteps - 1
+    t_start = t_start_of(cfg, dt.reduced)
     d.sa_start, d.s1m_start = float(dt.sqrt_ac[t_start]), float(dt.sqrt_1m_ac[t_start])
     d.y_dev, d.k_dev, d.mask_dev = _ptr(y), _ptr(k), _ptr(mask)
     lab = None
@@ -143,10 +166,13 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
         lab = np.ascontiguousarray(labels, dtype=np.int64)
         d.labels_host = lab.ctypes.data
     if noise_source == "host":
-        if noise_fn is None:
-            raise EngineError("noise_source='host' needs noise_fn")
         rp = cfg.generate_mode == "repaint"
-        drawn = draw_host_noise(noise_fn, steps, (B, 3, H, W), cfg.eta != 0, repaint=rp)
+        if predrawn is not None:                 # (init, n1, n2[, nrp]) already drawn in the reference's order (sharded runs)
+            drawn = predrawn
+        elif noise_fn is None:
+            raise EngineError("noise_source='host' needs noise_fn")
+        else:
+            drawn = draw_host_noise(noise_fn, steps, (B, 3, H, W), cfg.eta != 0, repaint=rp)
         init, n1, n2 = drawn[:3]
         if rp:
             drp = engine.to_device(drawn[3])
@@ -196,7 +222,7 @@ def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=No
         xs = y.numpy()
     else:
         xs = y.numpy() * mask.numpy().astype(np.float32)
-    t_start = cfg.num_train_timesteps - 1
+    t_start = t_start_of(cfg, dt.reduced)
     n0 = np.asarray(noise_fn(shape), np.float32)
     x.copy_from(dt.sqrt_ac[t_start] * (np.float32(2) * xs - np.float32(1)) + dt.sqrt_1m_ac[t_start] * n0)
     if cfg.task in ("sr", "deblur") and not (cfg.task == "sr" and cfg.sr_mode == "cubic"):

@@ -37,7 +37,11 @@ typedef enum dpir_status {
     DPIR_ERR_HIP = -2,       /* a HIP runtime call failed */
     DPIR_ERR_NOMEM = -3,
     DPIR_ERR_STATE = -4,     /* e.g. forward before load_unet */
-    DPIR_ERR_UNSUPPORTED = -5
+    DPIR_ERR_UNSUPPORTED = -5,
+    DPIR_ERR_RANGE = -6      /* f16x3 mode: an activation left the f16 operand range (|v| > 65000) and was clamped; the
+                              * result is wrong.  Reported by dpir_sync / dpir_d2h after the offending work; reload the
+                              * weights with dpir_set_precision(e, 0).  Mirrors the reference's use_fp16 caveat
+                              * (guided_diffusion/unet.py:618-632, fp16_util.py:15-32) -- but loudly. */
 } dpir_status;
 
 typedef struct dpir_engine dpir_engine;   /* opaque */
@@ -218,6 +222,8 @@ int dpir_prof_reset(dpir_engine* e);
 int dpir_prof_read(dpir_engine* e, double* ms_out, int64_t* count_out);
 /* FLOPs (2*MAC, conv+linear+attention) of one UNet forward for one image at HxW; 0 if no model */
 double dpir_unet_flops(dpir_engine* e, int H, int W);
+/* number of captured step graphs currently cached by dpir_run_loop (one per shape / task / mode, shared by all batches) */
+int dpir_graph_cache_size(dpir_engine* e);
 /* the same split by profiling class (0 conv3x3, 1 conv1x1 incl. qkv/proj_out, 3 attention matmuls, 5 linears; -1 total) */
 double dpir_unet_flops_class(dpir_engine* e, int H, int W, int cls);
 

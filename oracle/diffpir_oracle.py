@@ -94,10 +94,16 @@ class LoopConfig:
     beta_start: float = 0.0001
     beta_end: float = 0.02
     generate_mode: str = "DiffPIR"       # DiffPIR | repaint | vanilla (the latter two: inpainting only)
+    noise_init_img: object = "max"       # 'max' or a noise level in /255 units (main_ddpir.py:197-200)
 
     @property
     def sigma(self):                     # main_ddpir.py:141
         return max(0.001, self.noise_level_img)
+
+    def t_start(self, dt) -> int:        # main_ddpir.py:197-200
+        if self.noise_init_img == "max":
+            return self.T - 1
+        return find_nearest(dt.reduced, 2 * float(self.noise_init_img) / 255)
 
 
 def step_tables(cfg: LoopConfig):
@@ -309,7 +315,8 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
     y = y.float()
     if cfg.task == "inpaint":
         mask = mask.float()
-    x = init_x(cfg, y, mask, dt, noise_fn(torch.empty(y.shape[0], 3, y.shape[2] * cfg.sf, y.shape[3] * cfg.sf)))
+    t_start = cfg.t_start(dt)
+    x = init_x(cfg, y, mask, dt, noise_fn(torch.empty(y.shape[0], 3, y.shape[2] * cfg.sf, y.shape[3] * cfg.sf)), t_start)
     pre = None
     if cfg.task in ("sr", "deblur"):
         pre = pre_calculate(y, k.float(), cfg.sf)
@@ -317,6 +324,8 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
         raise ValueError("repaint / vanilla: inpainting only (main_ddpir.py:448 re-noises only for inpainting or DiffPIR)")
     for st in steps:
         t_i = st["t_i"]
+        if t_i > t_start:                           # main_ddpir.py:346-347: nothing runs (and nothing is drawn) above t_start
+            continue
         if cfg.generate_mode == "repaint":          # main_ddpir.py:355-358
             x = (dt.sqrt_ac[t_i] * (2 * y - 1) + dt.sqrt_1m_ac[t_i] * noise_fn(x)) * mask + (1 - mask) * x
         if denoiser is not None:

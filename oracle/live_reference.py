@@ -62,7 +62,9 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
     sqrt_alphas_cumprod = torch.sqrt(alphas_cumprod)
     sqrt_1m_alphas_cumprod = torch.sqrt(1. - alphas_cumprod)
     reduced_alpha_cumprod = torch.div(sqrt_1m_alphas_cumprod, sqrt_alphas_cumprod)
-    t_start = T - 1
+    # :197-200
+    nii = getattr(cfg, "noise_init_img", "max")
+    t_start = T - 1 if nii == 'max' else utils_model.find_nearest(reduced_alpha_cumprod, 2 * nii / 255)
     # :274-286
     sigmas, sigma_ks, rhos = [], [], []
     for i in range(T):
@@ -100,6 +102,8 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
         for i in range(len(seq)):
             curr_sigma = sigmas[seq[i]].cpu().numpy()
             t_i = utils_model.find_nearest(reduced_alpha_cumprod, curr_sigma)
+            if t_i > t_start:                                              # main_ddpir.py:346-347
+                continue
             gen_mode = getattr(cfg, "generate_mode", "DiffPIR")
             if cfg.task == "inpaint" and gen_mode == 'repaint':            # main_ddpir.py:355-358
                 x = (sqrt_alphas_cumprod[t_i] * (2 * y - 1) + sqrt_1m_alphas_cumprod[t_i] * torch.randn_like(x)) * mask \

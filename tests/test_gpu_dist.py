@@ -1,0 +1,58 @@
+"""-m gpu: the multi-GPU product path on ONE GPU.  Two processes (one engine each, both on device 0) restore a B=4 batch
+through diffpir_amd.dist.restore_sharded -- the function the YAML driver and bench.py call -- with the result all-gather on the
+`gloo` backend; the gathered uint8 batch must equal the single-process result bit for bit (device noise is keyed by the global
+image index, so sharding cannot change an image).  Covers even and ragged splits and the host-noise (parity) slicing."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _case(n):
+    from diffpir_amd import synth
+    return synth.make_case("deblur", n, 32, 32, seed=31, ksize=9)
+
+
+def _run(rank, world, port, n, noise, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0")
+    import torch
+    import diffpir_amd
+    from diffpir_amd import dist as ddist, restore
+    from oracle import unet_oracle as uo
+    from tests.gpu_common import make_model, seeded_noise_fn_np
+    r, _, w = ddist.init("gloo")
+    eng = diffpir_amd.Engine(0)
+    make_model(eng, uo.tiny_hp())
+    cfg = restore.LoopConfig(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3, eta=0.5 if noise == "host" else 0.0)
+    case = _case(n)
+    drawn = None
+    if noise == "host":                  # every rank draws the GLOBAL noise in the reference's order and keeps its image slice
+        _, steps, _ = restore._steps(cfg)
+        drawn = restore.draw_host_noise(seeded_noise_fn_np(77), steps, (n, 3, 32, 32), True)
+    u8, _ = ddist.restore_sharded(eng, cfg, case["y"], k=case["k"], rank=r, world=w, image_offset=100, seed=9, use_graph=True,
+                                  noise_source=noise, host_noise=drawn)
+    ret[rank] = u8.cpu().numpy().tobytes()
+    ddist.shutdown()
+    eng.close()
+
+
+@pytest.mark.parametrize("n,noise", [(4, "device"), (3, "device"), (4, "host")])
+def test_two_ranks_on_one_gpu_equal_one_rank(n, noise):
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    mp.spawn(_run, args=(1, _free_port(), n, noise, one), nprocs=1, join=True)
+    mp.spawn(_run, args=(2, _free_port(), n, noise, two), nprocs=2, join=True)
+    assert len(one[0]) == n * 32 * 32 * 3
+    assert two[0] == one[0] and two[1] == one[0]

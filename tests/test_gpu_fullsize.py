@@ -1,0 +1,254 @@
+"""-m gpu: parity at the BENCHED sizes and on the untested corners the round-1 review named.
+
+  * FFHQ topology at 256x256 against the LIVE-reference fixture (tests/golden/fullsize.npz) and the oracle;
+  * BASELINE config 2 (FFHQ 256x256 Gaussian deblur, 61x61 PSF) through the replayed hipGraph with the half-spectrum register
+    FFT reading tau from the device step block: 4 NFE vs the live reference, 8 NFE at B=2 vs the oracle, and ONE 100-NFE run;
+  * BASELINE config 3 topology (ImageNet-256, 552.8 M parameters) AT 256x256: per-layer taps (conv tiles 256->256@256^2,
+    512->256@256^2, attention T=1024) and the sf=4 bicubic-PSF loop;
+  * BASELINE config 5 topology (512x512 class-conditional), one forward with labels;
+  * an sf change on ONE engine (spectrum layout switch), f16x3 operand-range failure, schedule corner cases, graph reuse.
+Everything goes through the C ABI.  Both arithmetic modes.  Bounds: the north-star |dPSNR| <= 1e-3 dB plus a pixel bound of a few
+times the reference's own fp32 conditioning floor for the FFT prox; 2e-5 relative per UNet layer."""
+import numpy as np
+import pytest
+import torch
+
+import diffpir_amd
+from diffpir_amd import restore, synth
+from oracle import unet_oracle as uo, diffpir_oracle as do
+from tests.gpu_common import make_model, seeded_noise_fn_np, seeded_noise_fn_torch, rel_err
+
+pytestmark = pytest.mark.gpu
+PRECISIONS = ["f32", "f16x3"]
+TOL_LAYER = 2e-5
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def ffhq(request):
+    """(engine, state dict, precision) with the FFHQ topology loaded -- one per arithmetic mode for the whole module."""
+    e = diffpir_amd.Engine(0)
+    e.set_precision(request.param)
+    model, sd = make_model(e, uo.ffhq_hp())
+    yield e, sd, request.param
+    e.close()
+
+
+def _psnr_gap(out, ref, gt):
+    return abs(restore.psnr_batch(out * 2 - 1, gt * 2 - 1) - restore.psnr_batch(ref * 2 - 1, gt * 2 - 1))
+
+
+def test_ffhq_256_forward_matches_live_reference_fixture(ffhq, golden):
+    e, sd, precision = ffhq
+    g = golden("fullsize")
+    x = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(int(g["ffhq256_x_seed"]))).numpy()
+    out = e.unet_forward(e.to_device(x), g["ffhq256_t"]).numpy()
+    err = rel_err(out, g["ffhq256_out"])
+    print(f"ffhq 256^2 forward [{precision}] vs live reference: rel err {err:.3e}")
+    assert err < TOL_LAYER
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_c2_loop_matches_live_reference_fixture(ffhq, golden, graph):
+    """4 NFE of config 2 at full size: fft2.hip's rfft_rows / cfft_cols(solve) / irfft_rows at N=256 inside the loop."""
+    e, sd, precision = ffhq
+    g = golden("fullsize")
+    cfg = restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, g["c2_y"], k=g["c2_k"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["c2_seed"])),
+                                use_graph=graph).numpy()
+    err, gap = float(np.abs(out - g["c2_out"]).max()), _psnr_gap(out, g["c2_out"], g["c2_gt"])
+    print(f"C2 4-NFE [{precision}, graph={graph}] vs live reference: max|diff| {err:.3e}, |dPSNR| {gap:.2e} dB")
+    assert gap <= 1e-3 and err < 1.5e-2
+
+
+def test_c2_full_size_b2_8nfe_vs_oracle(ffhq):
+    e, sd, precision = ffhq
+    case = synth.make_case("deblur", 2, 256, 256, seed=7, ksize=61)
+    cfg = restore.LoopConfig(task="deblur", iter_num=8, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(61),
+                                use_graph=True).numpy()
+    ref = do.restore(sd, uo.ffhq_hp(), do.LoopConfig("deblur", 8, 12.75 / 255, 7.0, 0.3), torch.from_numpy(case["y"]),
+                     k=torch.from_numpy(case["k"]), noise_fn=seeded_noise_fn_torch(61)).numpy()
+    err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
+    print(f"C2 B=2 8-NFE [{precision}] vs oracle: max|diff| {err:.3e}, rms {np.sqrt(np.mean((out - ref) ** 2)):.3e}, |dPSNR| {gap:.2e} dB")
+    assert gap <= 1e-3 and err < 1.5e-2
+
+
+def test_c2_100_nfe_vs_oracle(ffhq):
+    """The north-star tolerance is stated at 100 NFE: one full-length run (B=1) of the benched configuration, graph replay,
+    against the oracle on identical y / k / weights / host-drawn noise.  ~100 s of oracle time on the host cores."""
+    e, sd, precision = ffhq
+    if precision != "f16x3":
+        pytest.skip("the 100-NFE run is made once, in the bench's default arithmetic mode (the f32 mode is covered at 8 NFE)")
+    case = synth.make_case("deblur", 1, 256, 256, seed=9, ksize=61)
+    cfg = restore.LoopConfig(task="deblur", iter_num=100, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(62),
+                                use_graph=True).numpy()
+    torch.set_num_threads(32)
+    ref = do.restore(sd, uo.ffhq_hp(), do.LoopConfig("deblur", 100, 12.75 / 255, 7.0, 0.3), torch.from_numpy(case["y"]),
+                     k=torch.from_numpy(case["k"]), noise_fn=seeded_noise_fn_torch(62)).numpy()
+    err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
+    print(f"C2 100-NFE [{precision}] vs oracle: max|diff| {err:.3e}, rms {np.sqrt(np.mean((out - ref) ** 2)):.3e}, |dPSNR| {gap:.2e} dB, "
+          f"PSNR {restore.psnr_batch(out * 2 - 1, case['gt'] * 2 - 1):.4f} dB")
+    assert gap <= 1e-3 and err < 1.5e-2
+
+
+@pytest.fixture(scope="module", params=PRECISIONS)
+def imagenet(request):
+    e = diffpir_amd.Engine(0)
+    e.set_precision(request.param)
+    model, sd = make_model(e, uo.imagenet256_hp())
+    yield e, sd, request.param
+    e.close()
+
+
+def test_imagenet256_topology_at_256_layers(imagenet):
+    """Config 3's network at its real input size, layer by layer: 256->256 and 512->256 tiles at 256^2, attention at T = 1024."""
+    e, sd, precision = imagenet
+    hp = uo.imagenet256_hp()
+    x = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(21))
+    t = torch.tensor([611])
+    taps = {}
+    ref = uo.unet_forward(sd, hp, x, t, None, taps=taps)
+    out = e.unet_forward(e.to_device(x.numpy()), t.numpy()).numpy()
+    worst = ("", 0.0)
+    for name, tv in taps.items():
+        if name == "emb":
+            continue
+        err = rel_err(e.read_tap(name).reshape(tv.shape), tv.numpy())
+        if err > worst[1]:
+            worst = (name, err)
+    err = rel_err(out, ref.numpy())
+    print(f"imagenet-256 @256^2 [{precision}]: output rel err {err:.3e}, worst layer {worst[0]} {worst[1]:.3e}")
+    assert worst[1] < TOL_LAYER and err < TOL_LAYER
+    assert e.unet_flops(256, 256) == pytest.approx(2239.67e9, rel=1e-3)
+
+
+def test_c3_sr4_loop_full_size_vs_oracle(imagenet, golden):
+    """Config 3 in miniature: ImageNet-256 topology, 64^2 -> 256^2, x4 bicubic PSF (kernels_bicubicx234[0,2]), 3 NFE, graph on."""
+    e, sd, precision = imagenet
+    kb = golden("operators")["k_bic4"]
+    case = synth.make_case("sr", 1, 256, 256, seed=3, sf=4)
+    k = kb[None, None].astype(np.float32)
+    cfg = restore.LoopConfig(task="sr", iter_num=3, lambda_=6.0, zeta=0.25, sf=4)
+    out = restore.restore_batch(e, cfg, case["y"], k=k, noise_source="host", noise_fn=seeded_noise_fn_np(63), use_graph=True).numpy()
+    ref = do.restore(sd, uo.imagenet256_hp(), do.LoopConfig("sr", 3, 12.75 / 255, 6.0, 0.25, sf=4), torch.from_numpy(case["y"]),
+                     k=torch.from_numpy(k), noise_fn=seeded_noise_fn_torch(63)).numpy()
+    err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
+    print(f"C3 sr x4 3-NFE [{precision}] vs oracle: max|diff| {err:.3e}, |dPSNR| {gap:.2e} dB")
+    assert gap <= 1e-3 and err < 1.5e-2
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_imagenet512_class_conditional_forward(precision):
+    """Config 5's network (script_util.py:149-150: channel_mult (0.5,1,1,2,2,4,4), class labels through model_kwargs,
+    unet.py:643-652): one 512x512 forward with a label against the oracle."""
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision(precision)
+        hp = uo.imagenet512_hp()
+        model, sd = make_model(e, hp)
+        x = torch.randn((1, 3, 512, 512), generator=torch.Generator().manual_seed(22))
+        t, y = torch.tensor([250]), torch.tensor([417])
+        ref = uo.unet_forward(sd, hp, x, t, y).numpy()
+        out = e.unet_forward(e.to_device(x.numpy()), t.numpy(), y.numpy()).numpy()
+        err = rel_err(out, ref)
+        print(f"imagenet-512 class-cond forward [{precision}]: rel err {err:.3e}, {e.unet_flops(512, 512) / 1e9:.1f} GFLOP")
+        assert err < TOL_LAYER
+        with pytest.raises(diffpir_amd.EngineError):
+            e.unet_forward(e.to_device(x.numpy()), t.numpy(), None)              # unet.py:643-645: y iff class-conditional
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("precision", PRECISIONS)
+def test_sf_change_on_one_engine_switches_the_spectrum_layout(precision):
+    """deblur (sf=1: half-spectrum register FFT at 64^2) -> sr-blur (sf=4: bit-reversed c2c) -> deblur again on ONE engine:
+    the engine-owned spectra must be re-allocated with the layout the new sf needs (round-1 advisor finding)."""
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision(precision)
+        hp = uo.tiny_hp()
+        model, sd = make_model(e, hp)
+        deb = synth.make_case("deblur", 2, 64, 64, seed=1, ksize=9)
+        srr = synth.make_case("sr", 2, 64, 64, seed=2, sf=4)
+        runs = [("deblur", deb, restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3), do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3)),
+                ("sr", srr, restore.LoopConfig(task="sr", iter_num=4, lambda_=6.0, zeta=0.25, sf=4), do.LoopConfig("sr", 4, 12.75 / 255, 6.0, 0.25, sf=4)),
+                ("deblur", deb, restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3), do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3))]
+        for name, case, cfg, ocfg in runs:
+            out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(70), use_graph=True).numpy()
+            ref = do.restore(sd, hp, ocfg, torch.from_numpy(case["y"]), k=torch.from_numpy(case["k"]), noise_fn=seeded_noise_fn_torch(70)).numpy()
+            assert np.isfinite(out).all()
+            assert _psnr_gap(out, ref, case["gt"]) <= 1e-3 and np.abs(out - ref).max() < 1.5e-2, name
+    finally:
+        e.close()
+
+
+def test_f16x3_operand_range_overflow_is_an_error_not_a_wrong_image():
+    """A checkpoint whose residual stream exceeds the f16 range (here: conv_in scaled by 1e6) saturates the operand split of the
+    1x1 skip projections.  f16x3 mode must FAIL (DPIR_ERR_RANGE at the next sync / D2H); f32 mode must still match the oracle."""
+    hp = uo.ffhq_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    sd = {k: v.clone() for k, v in sd.items()}
+    sd["input_blocks.0.0.weight"] *= 1e6
+    sd["input_blocks.0.0.bias"] *= 1e6
+    x = torch.randn((1, 3, 128, 128), generator=torch.Generator().manual_seed(5))     # 128^2: the 256->128 skip at full resolution runs on conv5
+    t = torch.tensor([500])
+    ref = uo.unet_forward(sd, hp, x, t).numpy()
+    from diffpir_amd import script_util, weights
+    for precision in PRECISIONS:
+        e = diffpir_amd.Engine(0)
+        try:
+            e.set_precision(precision)
+            model = script_util.create_model(**weights.create_model_kwargs(weights.model_hp("ffhq")), engine=e)
+            model.load_state_dict({k: v.numpy() for k, v in sd.items()})
+            if precision == "f16x3":
+                with pytest.raises(diffpir_amd.EngineRangeError, match="f16 operand range"):
+                    e.unet_forward(e.to_device(x.numpy()), t.numpy()).numpy()
+                e.sync()                                # the counter was consumed by the failing call: the engine stays usable
+            else:
+                out = e.unet_forward(e.to_device(x.numpy()), t.numpy()).numpy()
+                assert rel_err(out, ref) < 2e-4
+        finally:
+            e.close()
+
+
+@pytest.fixture(scope="module")
+def tiny_engine():
+    e = diffpir_amd.Engine(0)
+    e.set_precision("f16x3")
+    model, sd = make_model(e, uo.tiny_hp())
+    yield e, sd
+    e.close()
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_schedule_corner_cases_match_live_reference_fixture(tiny_engine, golden, graph):
+    """noise_init_img != 'max' (t_start below T-1, main_ddpir.py:197-200, 346) and quad skipping with iter_num > T/2 (two
+    steps with seq[i] == seq[-1], both dead denoiser calls) -- outputs of the live reference loop."""
+    e, sd = tiny_engine
+    g, lg = golden("fullsize"), golden("loops")
+    cfg = restore.LoopConfig(task="inpaint", iter_num=8, noise_level_img=0.0, lambda_=1.0, zeta=1.0, noise_init_img=float(g["tstart_noise_init_img"]))
+    out = restore.restore_batch(e, cfg, lg["inpaint_y"], mask=lg["inpaint_mask"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["tstart_seed"])),
+                                use_graph=graph).numpy()
+    assert np.abs(out - g["tstart_out"]).max() < 2e-3
+    cfg = restore.LoopConfig(task="inpaint", iter_num=520, noise_level_img=0.0, lambda_=1.0, zeta=1.0)
+    out = restore.restore_batch(e, cfg, lg["inpaint_y"], mask=lg["inpaint_mask"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["duplast_seed"])),
+                                use_graph=graph).numpy()
+    assert np.abs(out - g["duplast_out"]).max() < 5e-3
+
+
+def test_one_graph_serves_every_batch_of_a_shape(tiny_engine):
+    """Per-batch pointers, seed and image offset live in a device block, not in kernel arguments: a second batch with fresh
+    inputs replays the first batch's graphs (round-1 advisor finding: one capture per batch, never evicted)."""
+    e, sd = tiny_engine
+    cfg = restore.LoopConfig(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3)
+    a = synth.make_case("deblur", 2, 32, 32, seed=11, ksize=9)
+    b = synth.make_case("deblur", 2, 32, 32, seed=12, ksize=9)
+    o1 = restore.restore_batch(e, cfg, a["y"], k=a["k"], noise_source="device", seed=3, image_offset=0, use_graph=True).numpy()
+    n1 = e.graph_cache_size()
+    o2 = restore.restore_batch(e, cfg, b["y"], k=b["k"], noise_source="device", seed=3, image_offset=2, use_graph=True).numpy()
+    assert e.graph_cache_size() == n1 and n1 >= 2
+    # and the replayed graph really used the second batch's inputs: equal to an eager run of that batch
+    o2e = restore.restore_batch(e, cfg, b["y"], k=b["k"], noise_source="device", seed=3, image_offset=2, use_graph=False).numpy()
+    np.testing.assert_array_equal(o2, o2e)
+    assert np.abs(o1 - o2).max() > 1e-3

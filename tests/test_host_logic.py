@@ -217,3 +217,24 @@ def test_load_checkpoint_reads_a_reference_style_state_dict(tmp_path):
         assert got[k].dtype == np.float32
         ref = v.half().float().numpy() if i % 2 else v.numpy()
         np.testing.assert_array_equal(got[k], ref)
+
+
+def test_t_start_and_duplicate_final_steps_in_the_engine_step_table():
+    """noise_init_img / skip_noise_model_t reach the step table (round-1 advisor finding: silently dropped), and a quad schedule
+    with iter_num > T/2 yields TWO final steps, like the reference's `seq[i] == seq[-1]` test."""
+    from diffpir_amd import restore
+    from oracle import diffpir_oracle as do
+    cfg = restore.LoopConfig(task="inpaint", iter_num=8, noise_level_img=0.0, lambda_=1.0, zeta=1.0, noise_init_img=60.0)
+    dt, steps, arr = restore._steps(cfg)
+    ocfg = do.LoopConfig(task="inpaint", iter_num=8, noise_level_img=0.0, lambda_=1.0, zeta=1.0, noise_init_img=60.0)
+    odt, osteps = do.step_tables(ocfg)
+    t_start = ocfg.t_start(odt)
+    assert restore.t_start_of(cfg, dt.reduced) == t_start < 999
+    assert [s["t"] for s in steps] == [s["t_i"] for s in osteps if s["t_i"] <= t_start]
+    assert len(steps) < len(osteps)
+    dt, steps, arr = restore._steps(restore.LoopConfig(task="inpaint", iter_num=520, noise_level_img=0.0, lambda_=1.0, zeta=1.0))
+    assert [s["last"] for s in steps][-3:] == [0, 1, 1]
+    # skip_noise_model_t: accepted while the branch it guards is dead (iter_num <= T - noise_model_t), refused beyond
+    restore._steps(restore.LoopConfig(task="deblur", iter_num=100, skip_noise_model_t=True))
+    with pytest.raises(NotImplementedError):
+        restore._steps(restore.LoopConfig(task="deblur", iter_num=999, skip_noise_model_t=True))

@@ -188,3 +188,34 @@ def test_uniform_skip_loop_matches_live_reference(golden):
     nf = lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)
     out = do.restore(sd, hp, cfg, torch.from_numpy(g["inpaint_y"]), mask=torch.from_numpy(g["inpaint_mask"]), noise_fn=nf).numpy()
     assert np.abs(out - gm["inpaint_uniform_out"]).max() < 2e-5
+
+
+def test_full_size_fixtures_match_the_oracle(golden):
+    """tests/golden/fullsize.npz (oracle/gen_golden_fullsize.py, outputs of the LIVE reference): the FFHQ network at 256x256 and
+    four NFE of BASELINE config 2 at full size (61x61 PSF) -- the sizes the bench runs at."""
+    g = golden("fullsize")
+    hp = uo.ffhq_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    x = torch.randn((1, 3, 256, 256), generator=torch.Generator().manual_seed(int(g["ffhq256_x_seed"])))
+    out = uo.unet_forward(sd, hp, x, torch.from_numpy(g["ffhq256_t"]))
+    np.testing.assert_allclose(out.numpy(), g["ffhq256_out"], rtol=0, atol=1e-5)
+    cfg = do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3)
+    ref = do.restore(sd, hp, cfg, torch.from_numpy(g["c2_y"]), k=torch.from_numpy(g["c2_k"]), noise_fn=seeded_noise_fn(int(g["c2_seed"])))
+    np.testing.assert_allclose(ref.numpy(), g["c2_out"], rtol=0, atol=2e-5)
+
+
+def test_schedule_corner_cases_match_live_reference(golden):
+    """noise_init_img != 'max' (t_start, main_ddpir.py:197-200, 346) and quad skipping with two final steps (iter_num > T/2)."""
+    g, lg = golden("fullsize"), golden("loops")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    y, mask = torch.from_numpy(lg["inpaint_y"]), torch.from_numpy(lg["inpaint_mask"])
+    cfg = do.LoopConfig(task="inpaint", iter_num=8, noise_level_img=0.0, lambda_=1.0, zeta=1.0, noise_init_img=float(g["tstart_noise_init_img"]))
+    out = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(int(g["tstart_seed"])))
+    np.testing.assert_allclose(out.numpy(), g["tstart_out"], rtol=0, atol=2e-5)
+    dt, steps = do.step_tables(cfg)
+    assert sum(1 for s in steps if s["t_i"] > cfg.t_start(dt)) >= 1          # the fixture really skips steps
+    cfg = do.LoopConfig(task="inpaint", iter_num=520, noise_level_img=0.0, lambda_=1.0, zeta=1.0)
+    assert int(g["duplast_n_last"]) == 2
+    out = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(int(g["duplast_seed"])))
+    np.testing.assert_allclose(out.numpy(), g["duplast_out"], rtol=0, atol=2e-5)
