@@ -190,11 +190,16 @@ def data_solution(x, FB, FBC, F2B, FBFy, alpha, sf):
     return torch.real(torch.fft.ifftn(FX, dim=(-2, -1)))
 
 
-def prox_fft(x0, pre, tau, sf, guidance=1.0):
-    """main_ddpir.py:395-400."""
+def prox_fft(x0, pre, tau, sf, guidance=1.0, exact=False):
+    """main_ddpir.py:395-400.  exact=True evaluates the same closed form in float64 (spectra `pre` computed from float64
+    inputs by the caller) and rounds once at the end: the arithmetic-free yardstick against which the fp32 rounding noise of
+    the reference's own evaluation -- and the engine's -- is measured (the expression is ill-conditioned at small tau)."""
     FB, FBC, F2B, FBFy = pre
     x0_p = x0 / 2 + 0.5
-    x0_p = data_solution(x0_p.float(), FB, FBC, F2B, FBFy, tau, sf)
+    if exact:
+        x0_p = data_solution(x0_p.double(), FB, FBC, F2B, FBFy, tau.double(), sf).float()
+    else:
+        x0_p = data_solution(x0_p.float(), FB, FBC, F2B, FBFy, tau, sf)
     x0_p = x0_p * 2 - 1
     return x0 + guidance * (x0_p - x0)
 
@@ -302,13 +307,15 @@ def psnr_batch(a, b, max_pixel=2.0, eps=1e-10):
 
 
 def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = None, y_label=None,
-            trace: Optional[list] = None, denoiser: Optional[Callable] = None):
+            trace: Optional[list] = None, denoiser: Optional[Callable] = None, exact_prox: bool = False):
     """One batch of main_ddpir.py:259-470 (generate_mode DiffPIR / repaint / vanilla, pred_xstart, iter_num_U=1).
 
     y [B,3,h,w] in [0,1]; k [B,1,kh,kw] (deblur/sr-blur); mask [B,3,H,W] float {0,1} (inpaint).
     noise_fn(like) -> N(0,1) tensor; called in the reference's draw order (SURVEY 8 a-R):
     init, then per step: [repaint mix], p_sample, n1 (eta term), n2 (zeta term).
     `denoiser(x, t_i) -> x0` overrides the UNet (used to test the loop without a network).
+    exact_prox: the FFT data-fidelity step (and its pre-calculated spectra) in float64 -- NOT the reference's arithmetic; the
+    yardstick for the conditioning-aware parity bounds (tests/gpu_common.py::fft_prox_parity).
     Returns x_0 in [0,1] (un-clamped, main_ddpir.py:470)."""
     dt, steps = step_tables(cfg)
     dtab = DiffusionTables(cfg.T)
@@ -319,7 +326,7 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
     x = init_x(cfg, y, mask, dt, noise_fn(torch.empty(y.shape[0], 3, y.shape[2] * cfg.sf, y.shape[3] * cfg.sf)), t_start)
     pre = None
     if cfg.task in ("sr", "deblur"):
-        pre = pre_calculate(y, k.float(), cfg.sf)
+        pre = pre_calculate(y.double(), k.double(), cfg.sf) if exact_prox else pre_calculate(y, k.float(), cfg.sf)
     if cfg.generate_mode != "DiffPIR" and cfg.task != "inpaint":
         raise ValueError("repaint / vanilla: inpainting only (main_ddpir.py:448 re-noises only for inpainting or DiffPIR)")
     for st in steps:
@@ -342,7 +349,7 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
             elif cfg.task == "inpaint":
                 x0 = prox_mask(x0, y, mask, tau, cfg.guidance_scale)
             elif cfg.task == "deblur" or cfg.sr_mode == "blur":
-                x0 = prox_fft(x0, pre, tau, cfg.sf, cfg.guidance_scale)
+                x0 = prox_fft(x0, pre, tau, cfg.sf, cfg.guidance_scale, exact=exact_prox)
             else:
                 x0 = prox_ibp(x0, y, st["tau"], cfg.sf, cfg.gamma, cfg.inIter)
             n1 = noise_fn(x)

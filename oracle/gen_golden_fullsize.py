@@ -46,8 +46,14 @@ def main():
     with torch.no_grad():
         ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(51)).numpy()
         ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(51)).numpy()
-    out.update(c2_y=case["y"], c2_k=case["k"], c2_gt=case["gt"], c2_out=ref, c2_seed=np.array(51))
-    print("c2 4-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()))
+        # the reference's OWN fp32 rounding noise on this case: distance to the same loop with the (ill-conditioned) closed-form
+        # prox evaluated in float64 -- the yardstick of the conditioning-aware parity bound (tests/gpu_common.py::fft_prox_parity)
+        exact = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(51), exact_prox=True).numpy()
+    d = ref - exact
+    out.update(c2_y=case["y"], c2_k=case["k"], c2_gt=case["gt"], c2_out=ref, c2_seed=np.array(51),
+               c2_floor_max=np.array(np.abs(d).max()), c2_floor_rms=np.array(np.sqrt(np.mean(d * d))))
+    print("c2 4-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()),
+          "| reference vs exact-prox loop: max", float(np.abs(d).max()), "rms", float(np.sqrt(np.mean(d * d))))
 
     # schedule corner cases on the tiny UNet, inputs of tests/golden/loops.npz
     hp = uo.tiny_hp()

@@ -37,3 +37,49 @@ def rel_err(a, b):
     a = np.asarray(a, np.float64).reshape(-1)
     b = np.asarray(b, np.float64).reshape(-1)
     return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+_ORACLE_CACHE = {}
+
+
+def oracle_pair(key, sd, hp, ocfg, y, k, seed):
+    """(reference-arithmetic result, exact-prox result) of the oracle loop, cached per test key (both arithmetic modes of
+    the engine are compared with the same pair)."""
+    from oracle import diffpir_oracle as do
+    if key not in _ORACLE_CACHE:
+        ty, tk = torch.from_numpy(y), torch.from_numpy(k)
+        ref = do.restore(sd, hp, ocfg, ty, k=tk, noise_fn=seeded_noise_fn_torch(seed)).numpy()
+        exact = do.restore(sd, hp, ocfg, ty, k=tk, noise_fn=seeded_noise_fn_torch(seed), exact_prox=True).numpy()
+        _ORACLE_CACHE[key] = (ref, exact)
+    return _ORACLE_CACHE[key]
+
+
+def fft_prox_parity(out, ref, gt, label, exact=None, floor=None):
+    """Parity gate for loops through the FFT data-fidelity step.
+
+    The reference's closed form (utils_sisr.py:65-75) divides a near-cancelling difference by alpha = tau (7e-7 at the first
+    steps of config 2): its OWN fp32 evaluation differs from exact arithmetic by ~4e-2 per call there, and after a few NFE the
+    final image still carries that rounding noise (it is contracted away by ~100 NFE).  Two fp32 implementations therefore agree
+    only to the reference's own rounding-noise level, which is measured, not guessed: `exact` is the oracle loop with the prox in
+    float64 (same UNet, same noise), floor = (max, rms) of |ref - exact|.  Asserted:
+      * |dPSNR| <= 1e-3 dB                                   (north-star tolerance)
+      * engine vs reference   : rms <= floor rms, max <= 1.5 x floor max  (closer to the reference than the reference is to exact)
+      * engine vs exact       : rms <= 1.25 x floor rms                  (not less accurate than the reference)"""
+    from diffpir_amd import restore
+    if floor is None:
+        d = ref - exact
+        floor = (float(np.abs(d).max()), float(np.sqrt(np.mean(d * d))))
+    e = out - ref
+    emax, erms = float(np.abs(e).max()), float(np.sqrt(np.mean(e * e)))
+    gap = abs(restore.psnr_batch(out * 2 - 1, gt * 2 - 1) - restore.psnr_batch(ref * 2 - 1, gt * 2 - 1))
+    msg = (f"{label}: engine-vs-reference max {emax:.3e} rms {erms:.3e} | reference-vs-exact (its own fp32 noise) max {floor[0]:.3e} "
+           f"rms {floor[1]:.3e} | |dPSNR| {gap:.2e} dB")
+    if exact is not None:
+        x = out - exact
+        xrms = float(np.sqrt(np.mean(x * x)))
+        msg += f" | engine-vs-exact rms {xrms:.3e}"
+        assert xrms <= 1.25 * floor[1] + 1e-6, msg
+    print(msg)
+    assert gap <= 1e-3, msg
+    assert erms <= floor[1] + 1e-6 and emax <= 1.5 * floor[0] + 1e-5, msg
+    return emax, erms, gap

@@ -7,8 +7,9 @@
     512->256@256^2, attention T=1024) and the sf=4 bicubic-PSF loop;
   * BASELINE config 5 topology (512x512 class-conditional), one forward with labels;
   * an sf change on ONE engine (spectrum layout switch), f16x3 operand-range failure, schedule corner cases, graph reuse.
-Everything goes through the C ABI.  Both arithmetic modes.  Bounds: the north-star |dPSNR| <= 1e-3 dB plus a pixel bound of a few
-times the reference's own fp32 conditioning floor for the FFT prox; 2e-5 relative per UNet layer."""
+Everything goes through the C ABI.  Both arithmetic modes.  Bounds: 2e-5 relative per UNet layer; for loops through the FFT prox
+the north-star |dPSNR| <= 1e-3 dB plus pixel bounds tied to the reference's own measured fp32 rounding noise
+(tests/gpu_common.py::fft_prox_parity); at 100 NFE, where that noise has been contracted away, max |diff| <= 1e-3."""
 import numpy as np
 import pytest
 import torch
@@ -16,7 +17,7 @@ import torch
 import diffpir_amd
 from diffpir_amd import restore, synth
 from oracle import unet_oracle as uo, diffpir_oracle as do
-from tests.gpu_common import make_model, seeded_noise_fn_np, seeded_noise_fn_torch, rel_err
+from tests.gpu_common import make_model, seeded_noise_fn_np, seeded_noise_fn_torch, rel_err, oracle_pair, fft_prox_parity
 
 pytestmark = pytest.mark.gpu
 PRECISIONS = ["f32", "f16x3"]
@@ -55,9 +56,8 @@ def test_c2_loop_matches_live_reference_fixture(ffhq, golden, graph):
     cfg = restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3)
     out = restore.restore_batch(e, cfg, g["c2_y"], k=g["c2_k"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["c2_seed"])),
                                 use_graph=graph).numpy()
-    err, gap = float(np.abs(out - g["c2_out"]).max()), _psnr_gap(out, g["c2_out"], g["c2_gt"])
-    print(f"C2 4-NFE [{precision}, graph={graph}] vs live reference: max|diff| {err:.3e}, |dPSNR| {gap:.2e} dB")
-    assert gap <= 1e-3 and err < 1.5e-2
+    fft_prox_parity(out, g["c2_out"], g["c2_gt"], f"C2 4-NFE [{precision}, graph={graph}] vs LIVE reference",
+                    floor=(float(g["c2_floor_max"]), float(g["c2_floor_rms"])))
 
 
 def test_c2_full_size_b2_8nfe_vs_oracle(ffhq):
@@ -66,11 +66,8 @@ def test_c2_full_size_b2_8nfe_vs_oracle(ffhq):
     cfg = restore.LoopConfig(task="deblur", iter_num=8, lambda_=7.0, zeta=0.3)
     out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(61),
                                 use_graph=True).numpy()
-    ref = do.restore(sd, uo.ffhq_hp(), do.LoopConfig("deblur", 8, 12.75 / 255, 7.0, 0.3), torch.from_numpy(case["y"]),
-                     k=torch.from_numpy(case["k"]), noise_fn=seeded_noise_fn_torch(61)).numpy()
-    err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
-    print(f"C2 B=2 8-NFE [{precision}] vs oracle: max|diff| {err:.3e}, rms {np.sqrt(np.mean((out - ref) ** 2)):.3e}, |dPSNR| {gap:.2e} dB")
-    assert gap <= 1e-3 and err < 1.5e-2
+    ref, exact = oracle_pair("c2_b2_8nfe", sd, uo.ffhq_hp(), do.LoopConfig("deblur", 8, 12.75 / 255, 7.0, 0.3), case["y"], case["k"], 61)
+    fft_prox_parity(out, ref, case["gt"], f"C2 B=2 8-NFE [{precision}] vs oracle", exact=exact)
 
 
 def test_c2_100_nfe_vs_oracle(ffhq):
@@ -89,7 +86,7 @@ def test_c2_100_nfe_vs_oracle(ffhq):
     err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
     print(f"C2 100-NFE [{precision}] vs oracle: max|diff| {err:.3e}, rms {np.sqrt(np.mean((out - ref) ** 2)):.3e}, |dPSNR| {gap:.2e} dB, "
           f"PSNR {restore.psnr_batch(out * 2 - 1, case['gt'] * 2 - 1):.4f} dB")
-    assert gap <= 1e-3 and err < 1.5e-2
+    assert gap <= 1e-3 and err < 1e-3          # the early steps' rounding noise is gone by 100 NFE: a tight pixel bound holds
 
 
 @pytest.fixture(scope="module", params=PRECISIONS)
@@ -131,11 +128,8 @@ def test_c3_sr4_loop_full_size_vs_oracle(imagenet, golden):
     k = kb[None, None].astype(np.float32)
     cfg = restore.LoopConfig(task="sr", iter_num=3, lambda_=6.0, zeta=0.25, sf=4)
     out = restore.restore_batch(e, cfg, case["y"], k=k, noise_source="host", noise_fn=seeded_noise_fn_np(63), use_graph=True).numpy()
-    ref = do.restore(sd, uo.imagenet256_hp(), do.LoopConfig("sr", 3, 12.75 / 255, 6.0, 0.25, sf=4), torch.from_numpy(case["y"]),
-                     k=torch.from_numpy(k), noise_fn=seeded_noise_fn_torch(63)).numpy()
-    err, gap = float(np.abs(out - ref).max()), _psnr_gap(out, ref, case["gt"])
-    print(f"C3 sr x4 3-NFE [{precision}] vs oracle: max|diff| {err:.3e}, |dPSNR| {gap:.2e} dB")
-    assert gap <= 1e-3 and err < 1.5e-2
+    ref, exact = oracle_pair("c3_sr4_3nfe", sd, uo.imagenet256_hp(), do.LoopConfig("sr", 3, 12.75 / 255, 6.0, 0.25, sf=4), case["y"], k, 63)
+    fft_prox_parity(out, ref, case["gt"], f"C3 sr x4 3-NFE [{precision}] vs oracle", exact=exact)
 
 
 @pytest.mark.parametrize("precision", PRECISIONS)
@@ -176,9 +170,9 @@ def test_sf_change_on_one_engine_switches_the_spectrum_layout(precision):
                 ("deblur", deb, restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3), do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3))]
         for name, case, cfg, ocfg in runs:
             out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(70), use_graph=True).numpy()
-            ref = do.restore(sd, hp, ocfg, torch.from_numpy(case["y"]), k=torch.from_numpy(case["k"]), noise_fn=seeded_noise_fn_torch(70)).numpy()
+            ref, exact = oracle_pair("sfswitch_" + name, sd, hp, ocfg, case["y"], case["k"], 70)
             assert np.isfinite(out).all()
-            assert _psnr_gap(out, ref, case["gt"]) <= 1e-3 and np.abs(out - ref).max() < 1.5e-2, name
+            fft_prox_parity(out, ref, case["gt"], f"sf switch / {name} [{precision}]", exact=exact)
     finally:
         e.close()
 
