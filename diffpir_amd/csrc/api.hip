@@ -4,6 +4,7 @@
 #include "engine.h"
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 using namespace dpir;
 
@@ -113,6 +114,7 @@ int dpir_create(int device, dpir_engine** out) {
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DPIR_ERR_HIP; }
     e->prof.stream = e->stream;
+    if (const char* ci = getenv("DIFFPIR_CONV")) e->conv_impl = atoi(ci) == 4 ? 4 : 6;      // developer A/B switches
     if (hipMalloc((void**)&e->range_ctr, sizeof(unsigned long long)) != hipSuccess ||
         hipMemset(e->range_ctr, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
     *out = e;
@@ -749,7 +751,8 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
         std::vector<uint16_t> w16h;
         std::vector<uint16_t>& w16v = w16h;
-        w16_scale = ks == 1 ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16v) : pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16v);
+        w16_scale = ks == 1 ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16v)
+                            : ((dbg & 4096) ? pack_weights_conv6(hw.data(), Cout, Cin, w16v) : pack_weights_f16x3(hw.data(), Cout, Cin, ks, w16v));
         void* wp = nullptr;
         API_TRY(e, e->ws.get("dbg#w16", w16v.size() * 2, &wp));
         API_HIP(e, hipMemcpy(wp, w16v.data(), w16v.size() * 2, hipMemcpyHostToDevice));
@@ -774,8 +777,18 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         a4.B = B; a4.Cin = Cin; a4.Cout = Cout; a4.H = H; a4.W = W; a4.partial = partial; a4.partial_capacity = a.partial_capacity;
         a4.dbg = (dbg & 31) | (dbg & (1024 | 2048));
     }
+    Conv6Args a6;
+    const bool use6 = use4 && (dbg & 4096) != 0;        // dbg 64 | 128 | 4096: conv6 (+ 256: without the act_split pre-pass)
+    if (use6) {
+        a6.xhi = a4.xhi; a6.xlo = a4.xlo; a6.w16 = w16; a6.w16_scale = w16_scale; a6.bias = bias; a6.out = out;
+        a6.B = B; a6.Cin = Cin; a6.Cout = Cout; a6.H = H; a6.W = W; a6.partial = partial; a6.partial_capacity = a.partial_capacity;
+    }
     auto run_once = [&]() -> Status {
         if (use5) return launch_conv5(e->stream, a5);
+        if (use6) {
+            if (!(dbg & 256)) DPIR_TRY(launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, const_cast<void*>(a6.xhi), const_cast<void*>(a6.xlo)));
+            return launch_conv6(e->stream, a6);
+        }
         if (!use4) return launch_conv(e->stream, a);
         if (!(dbg & 256)) DPIR_TRY(launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, mode, B, H, W, const_cast<void*>(a4.xhi), const_cast<void*>(a4.xlo)));
         return launch_conv4(e->stream, a4);

@@ -131,6 +131,20 @@ struct Conv4Args {
 bool conv4_supported(int H, int W);
 int conv4_stat_slots(int H, int W);
 Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written = nullptr);
+// conv6.hip: 3x3, f16x3, two workgroups per CU (private weight rings); same activation planes as conv4
+struct Conv6Args {
+    const void* xhi = nullptr; const void* xlo = nullptr;
+    const void* w16 = nullptr; float w16_scale = 1.f;       // pack_weights_conv6 layout
+    const float* bias = nullptr; float* out = nullptr; const float* res = nullptr; int res_mode = 0;
+    int B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
+    float* partial = nullptr; size_t partial_capacity = 0;
+    float2* stat = nullptr;        // optional [B][Cout][conv6_stat_slots(H, W)] epilogue partial sums (no split-K)
+    double2* stat_plane = nullptr; // optional [B][Cout] fp64 {sum, sum of squares}, written by the split-K combine
+};
+bool conv6_supported(int H, int W);
+int conv6_stat_slots(int H, int W);
+Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out = nullptr);
+float pack_weights_conv6(const float* w_oihw, int cout, int cin, std::vector<uint16_t>& out);
 // conv5.hip: 1x1 convolution, f16x3 with the operand split done in-kernel from the fp32 NCHW (virtual concat) input
 struct Conv5Args {
     CatSrc src; const float4* prm = nullptr;

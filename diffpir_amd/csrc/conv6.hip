@@ -1,0 +1,564 @@
+// conv6: 3x3 implicit-GEMM convolution on the f16 matrix pipe with operand splitting (x = hi + lo, three
+// v_mfma_f32_32x32x16_f16 per fp32-equivalent product, see conv4.hip) -- the TWO-WORKGROUPS-PER-CU generation.
+//
+// Why a new structure.  conv4 keeps one 156 KiB workgroup per CU: its prologue (first operand DMA, ~2 us), its epilogue
+// (64 co x 512 px fp32 = 128 KiB of stores + as much residual, bound by the per-CU store issue rate: 6-9 us) and its
+// barrier bubbles are all serialised with the MFMA stream -- at Cin = 128 the matrix pipe is busy 27.6 us of a 55 us
+// workgroup lifetime.  Here a workgroup needs 76 KiB of LDS and <= 256 VGPRs, so the hardware keeps TWO resident per CU
+// (two waves per SIMD, one from each) and one workgroup's prologue / epilogue / barrier waits run under the other's MFMAs.
+//
+// What made the LDS fit.  The 36 KiB weight stage of conv4 (64 co x 16 ci x 9 taps x hi/lo, shared by 8 waves, double
+// buffered = 72 KiB) is gone: the workgroup tile is 128 output channels x 256 pixels and each of the 4 waves owns
+// 32 output channels x ALL 256 pixels, so no two waves of a workgroup need the same weights.  Every wave streams its own
+// A operands (one 2 KiB piece per tap: hi + lo fragments of 32 co x 16 ci, stored by the host in lane order) through a
+// PRIVATE ring of R slots by LDS-DMA, ordered by nothing but the wave's own counted s_waitcnt vmcnt -- no barrier, no
+// sharing.  Only the activation patch (hi + lo, 11-13 KiB per plane, the blocked [n][C/8][H][W][8] tensor of act.hip) is
+// shared and double buffered: one workgroup barrier per 16-channel K chunk, as before.  Per unit of work the activation
+// DMA traffic is a quarter of conv4's (one patch feeds 128 output channels instead of 64, 256-pixel patch), the weight
+// DMA traffic is equal.
+//
+// Per K chunk and wave: 9 taps x 8 pixel tiles x 3 = 216 MFMAs (accumulators 8 x 16 = 128 registers), 9 x 18
+// ds_read_b128 (2 A + 16 B fragments per tap, B in four groups of two tiles so the next operands are requested while
+// the previous group's MFMAs are queued), 18 weight pieces + 6-8 activation pieces of LDS-DMA.
+//
+// Tile geometries (256 pixels): 8 rows x 32 columns (W >= 32), 16 x 16 (W >= 16), 4 images x 8 x 8 (W >= 8).
+#include "common.h"
+#include <math.h>
+#include <type_traits>
+#include <vector>
+
+namespace dpir {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+struct Conv6K {
+    const char* xhi; const char* xlo;      // blocked split activations [n][C8][H][W][16 B]
+    int C8;
+    const char* w16; const float* bias; float* out; const float* res; int res_mode;
+    int B, Cout, H, W;
+    int n_chunks_total;
+    int tiles_x, tiles_y, n_co_blocks;
+    int ksplit, chunks_per_split;
+    float* partial;
+    const float* zeros;
+    float out_scale;
+    float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
+};
+
+// LDS-DMA through a buffer descriptor: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The descriptor (4 SGPRs) and
+// the scalar offset carry everything wave-uniform, so a DMA instruction costs ONE live VGPR (the per-lane byte offset) and
+// no vector address arithmetic; a per-lane offset >= num_records is out of range and the hardware writes ZEROS for that
+// lane -- which is how the halo positions outside the image (and the padding of the last piece) are produced.
+#define BLDS6(rsrc, dst, voff, soff) \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(dst), 16, (voff), (soff), 0, 0)
+constexpr unsigned kOutOfRange = 0xFFFFFFFFu;
+// Descriptor from values that ARE wave-uniform but that the compiler cannot always prove so: without the readfirstlane it
+// wraps every buffer operation in a "waterfall" loop (v_readfirstlane x4, compare, s_and_saveexec, op, loop).
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_uniform(const void* ptr, unsigned bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
+                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
+}
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr6(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int GEO> struct Geo6;
+template <> struct Geo6<0> { static constexpr int LTW = 5, LTH = 3, TI = 1; };   // 8 rows x 32 columns
+template <> struct Geo6<1> { static constexpr int LTW = 4, LTH = 4, TI = 1; };   // 16 x 16
+template <> struct Geo6<2> { static constexpr int LTW = 3, LTH = 3, TI = 4; };   // 4 images x 8 x 8
+
+// s_waitcnt with only the vector-memory counter constrained (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    static_assert(N >= 0 && N < 64, "vmcnt range");
+    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
+    asm volatile("" ::: "memory");
+}
+
+// DMA instructions issued by the group of tap i of a chunk (i < 0: tap i + 9 of the previous chunk, always a MORE body):
+// [one activation piece of the next chunk if i < nact] + [the two weight pieces of tap i + d]
+constexpr int c6_gsize(bool more, int nact, int d, int i) {
+    const int j = i < 0 ? i + 9 : i;
+    const bool m = i < 0 ? true : more;
+    return ((m && j < nact) ? 1 : 0) + ((m || j + d < 9) ? 2 : 0);
+}
+// number of DMA instructions issued AFTER the weights of tap + 1 at the point where they are read (after the group of `tap`)
+constexpr int c6_wait_n(bool more, int nact, int d, int tap) {
+    int s = 0;
+    for (int i = tap + 2 - d; i <= tap; ++i) s += c6_gsize(more, nact, d, i);
+    return s;
+}
+
+template <int GEO, int R>
+__global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
+    // The body uses the buffer-descriptor builtin type, which only exists in the DEVICE pass of hipcc; in the host pass an
+    // (ill-formed) template body would silently drop the kernel's launch stub, so the host pass sees an empty body.
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Geo6<GEO>;
+    constexpr int TW = 1 << G::LTW, TH = 1 << G::LTH, TI = G::TI;
+    constexpr int LW = TW + 2, LH = TH + 2;
+    constexpr int PATCH = TI * LH * LW;                 // patch positions = entries per k-half
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;       // 1 KiB DMA pieces per plane (hi or lo)
+    constexpr int NXT = (NPIECE + 3) / 4;               // pieces per wave per plane
+    constexpr int NACT = 2 * NXT;                       // activation DMA instructions per wave per chunk
+    constexpr int XB = NPIECE * 1024;                   // bytes per plane buffer
+    constexpr int D = R - 1;                            // weight prefetch distance in taps
+    constexpr int TAPS = 9;
+    constexpr int GPI = (TW * TH) / 64;                 // 64-pixel groups per image inside one tile
+    static_assert(NACT <= TAPS, "one activation piece per tap");
+    extern __shared__ __attribute__((aligned(16))) char smem6[];
+    char* lds_x = smem6;                                // [2 buffers][hi|lo][XB]
+    char* lds_w = smem6 + 4 * XB;                       // [4 waves][R slots][hi 1 KiB | lo 1 KiB]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    // XCD-aware order (conv4.hip): one XCD owns a contiguous range of tiles
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
+    const int co_blk = bid % p.n_co_blocks;
+    const int ptile = bid / p.n_co_blocks;
+    const int co0 = co_blk * 128 + wave * 32;           // this wave's first output channel
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int img_grp = ptile / tiles_per_img;
+    const int trem = ptile - img_grp * tiles_per_img;
+    const int ty0 = (trem / p.tiles_x) * TH;
+    const int tx0 = (trem % p.tiles_x) * TW;
+    const int n0 = img_grp * TI;
+    const int HW = p.H * p.W;
+    const bool wave_live = co0 < p.Cout;                // waves beyond Cout multiply zero-padded weights and store nothing
+
+    // ---- per-lane DMA source offsets of this wave's activation pieces (chunk invariant, BYTES from the first entry of the
+    // chunk's first channel group); out-of-image positions get kOutOfRange (hardware zero fill).
+    // Piece indices beyond the plane are clamped onto its last piece (same data written twice) so that every wave issues the
+    // same number of DMA instructions: the counted vmcnt waits below rely on it.
+    unsigned x_off[NXT];
+#pragma unroll
+    for (int u = 0; u < NXT; ++u) {
+        int piece = wave + u * 4;
+        if (piece > NPIECE - 1) piece = NPIECE - 1;
+        const int f = piece * 64 + lane;
+        const int kg = f / PATCH;
+        const int e = f - kg * PATCH;
+        const int ti = e / (LH * LW);
+        const int rr = e - ti * (LH * LW);
+        const int hy = rr / LW, hx = rr - hy * LW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const int n = n0 + ti;
+        const bool ok = kg < 2 && n < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        x_off[u] = ok ? ((unsigned)((n * p.C8 + kg) * HW + gy * p.W + gx) << 4) : kOutOfRange;
+    }
+    // ---- MFMA operand addressing.  B fragment of pixel tile j, tap (dy, dx): entry lane_b + tile_off(j) + dy * LW + dx
+    const int lane_b = (GEO == 0 ? l31 : (GEO == 1 ? (l31 >> 4) * LW + (l31 & 15) : (l31 >> 3) * LW + (l31 & 7))) + half * PATCH;
+    auto tile_off = [](int j) constexpr -> int { return GEO == 0 ? j * LW : (GEO == 1 ? 2 * j * LW : (j >> 1) * (LH * LW) + (j & 1) * 4 * LW); };
+    const half8* xbase = reinterpret_cast<const half8*>(lds_x) + lane_b;
+    char* ring = lds_w + wave * (R * 2048);             // this wave's private weight ring
+    const half8* abase = reinterpret_cast<const half8*>(ring) + lane;
+
+    floatx16 acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+    const int ch_begin = split * p.chunks_per_split;
+    const int ch_end = min(p.n_chunks_total, ch_begin + p.chunks_per_split);
+    const int n_taps_total = (ch_end - ch_begin) * TAPS;
+
+    // weights of global tap g (counted from this block's first chunk) -> ring slot g % R: two 1 KiB pieces (hi, lo).
+    // This wave's records of one chunk are 18 KiB contiguous; the descriptor base moves with the chunk, the tap is the scalar offset.
+    const unsigned lane16 = (unsigned)lane * 16u;
+    const char* wsrc0 = p.w16 + ((((size_t)ch_begin * p.n_co_blocks + co_blk) * 4 + wave) * TAPS) * 2048;
+    const size_t wchunk_stride = (size_t)p.n_co_blocks * 4 * TAPS * 2048;
+    auto dma_w = [&](int chunk_rel, int tap, int slot) __attribute__((always_inline)) {
+        const __amdgpu_buffer_rsrc_t rw = rsrc_uniform(wsrc0 + (size_t)chunk_rel * wchunk_stride, TAPS * 2048);
+        char* dst = ring + slot * 2048;
+        BLDS6(rw, dst, lane16, tap * 2048);
+        BLDS6(rw, dst + 1024, lane16, tap * 2048 + 1024);
+    };
+    // activation piece q (0 .. NACT-1: u = q / 2, plane = q & 1) of chunk `chunk` -> buffer buf.  One chunk = two channel groups
+    // of HW entries; the descriptor base moves with the chunk, num_records = the plane (valid offsets never leave it).
+    const size_t xplane_bytes = (size_t)p.B * p.C8 * HW * 16;
+    auto dma_x = [&](int chunk, int buf, int q) __attribute__((always_inline)) {
+        const int u = q >> 1, plane = q & 1;
+        int piece = wave + u * 4;
+        if (piece > NPIECE - 1) piece = NPIECE - 1;
+        const size_t coff = (size_t)chunk * 2 * HW * 16;
+        const __amdgpu_buffer_rsrc_t rx = rsrc_uniform((plane ? p.xlo : p.xhi) + coff, (unsigned)(xplane_bytes - coff));
+        BLDS6(rx, lds_x + buf * 2 * XB + plane * XB + piece * 1024, x_off[u], 0);
+    };
+
+    // ---- prologue: the first chunk's patch and the first D taps of weights, all waited for
+#pragma unroll
+    for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+#pragma unroll
+    for (int g = 0; g < D; ++g)
+        if (g < n_taps_total) dma_w(g / TAPS, g % TAPS, g % R);
+    wait_vmcnt<0>();            // explicit: the compiler does not know that the ds_reads below depend on the LDS-DMA
+    __syncthreads();
+
+    half8 a_h[2], a_l[2];            // A fragments of the current / next tap
+    half8 b_h[2][2], b_l[2][2];      // B fragments of two pixel tiles, two register sets (one in use, one being filled)
+    auto read_a = [&](int slot, int rs) __attribute__((always_inline)) {
+        const half8* w = abase + slot * 128;           // 2048 B per slot = 128 entries
+        a_h[rs] = w[0];
+        a_l[rs] = w[64];
+    };
+    auto read_b = [&](int buf, int tap, int grp, int set) __attribute__((always_inline)) {      // pixel tiles 2 grp, 2 grp + 1
+        const half8* xh = xbase + buf * (2 * XB / 16);
+        const half8* xl = xh + XB / 16;
+        const int toff = (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = tile_off(grp * 2 + j) + toff;
+            b_h[set][j] = xh[o];
+            b_l[set][j] = xl[o];
+        }
+    };
+    auto mfma_group = [&](int grp, int set, int rs) __attribute__((always_inline)) {
+        // the three partial products of one accumulator are issued two MFMAs apart; small terms first
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[rs], b_h[set][j], acc[grp * 2 + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[rs], b_l[set][j], acc[grp * 2 + j], 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[rs], b_h[set][j], acc[grp * 2 + j], 0, 0, 0);
+    };
+
+    read_a(0, 0); read_b(0, 0, 0, 0);
+
+    // One K chunk.  MORE: a further chunk follows (its patch and the weights D taps ahead are prefetched).
+    // A tap = four groups of two pixel tiles (6 MFMAs each); the operands of the next group are requested before the MFMAs of
+    // the current one are issued, into the other register set.
+    // DMA group of tap i: [activation piece i of the next chunk, if i < NACT] + [the 2 weight pieces of tap i + D]; the weights
+    // of tap t+1 are therefore followed, in issue order, by the groups of taps t+2-D .. t, whose sizes are compile-time
+    // constants: that sum is the vmcnt that proves the tap t+1 pieces have landed (vector-memory loads complete in order).
+    auto chunk_body = [&](auto more_c, int chunk, int it) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const int cur = it & 1;
+        const int rbase = (it * TAPS) % R;              // ring slot of this chunk's tap 0
+        static_for<0, TAPS>([&](auto tap_c) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int rs = tap & 1;
+            read_b(cur, tap, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE && tap < NACT) dma_x(chunk + 1, cur ^ 1, tap);
+            if (MORE || tap + D < TAPS) {
+                const int g = tap + D;
+                dma_w(it + g / TAPS, g % TAPS, (rbase + g) % R);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 0, rs);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(cur, tap, 2, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, 1, rs);
+            __builtin_amdgcn_sched_barrier(0);
+            read_b(cur, tap, 3, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(2, 0, rs);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) {
+                wait_vmcnt<c6_wait_n(MORE, NACT, D, tap)>();
+                read_a((rbase + tap + 1) % R, (tap + 1) & 1);
+                read_b(cur, tap + 1, 0, 0);
+            } else if (MORE) {
+                // chunk boundary.  Before the barrier: this wave's activation pieces of the next chunk have landed (they
+                // are followed by their group's weights and the groups of taps NACT .. 8).  The barrier (with its lgkmcnt(0))
+                // then says every wave is done reading the current patch and writing / receiving the next one.  After it: the
+                // weights of the next chunk's tap 0 (followed by the groups of taps 11-D .. 8) -- an EXPLICIT wait: the compiler
+                // does not know that a ds_read depends on an LDS-DMA and may leave vmcnt out of the barrier's wait.
+                wait_vmcnt<2 + 2 * (TAPS - NACT)>();
+                __syncthreads();
+                wait_vmcnt<c6_wait_n(true, NACT, D, TAPS - 1)>();
+                read_a((rbase + TAPS) % R, 1);
+                read_b(cur ^ 1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(3, 1, rs);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        if (MORE) { a_h[0] = a_h[1]; a_l[0] = a_l[1]; }     // 9 taps: the next chunk's tap 0 uses register set 0 again
+    };
+    {   // all chunks but the last in a loop with ONE body (a branch between two bodies inside the loop keeps the register
+        // coalescer from unifying the accumulators across the back edge: two live copies of 128 registers), then the last
+        int it = 0, chunk = ch_begin;
+        for (; chunk + 1 < ch_end; ++chunk, ++it) chunk_body(std::true_type{}, chunk, it);
+        chunk_body(std::false_type{}, chunk, it);
+    }
+
+    // ---- epilogue: per wave, four passes of 32 co x 64 px through a private LDS slab (transposition to float4 rows of 4
+    // consecutive pixels), bias / residual / GroupNorm partial sums fused.  The other workgroup on this CU keeps the matrix
+    // pipe busy meanwhile.
+    __syncthreads();                                         // all waves are done with the operand buffers
+    constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
+    float* tr = reinterpret_cast<float*>(smem6) + wave * (32 * TS);
+    if (!wave_live) return;
+    const int q4 = lane & 15, rsub = lane >> 4;
+    float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
+    const bool do_stat = p.stat != nullptr && p.ksplit == 1;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int pp = q * 64 + q4 * 4;
+        const int px = pp & (TW - 1);
+        const int py = (pp >> G::LTW) & (TH - 1);
+        const int ti = pp >> (G::LTW + G::LTH);
+        const int n = n0 + ti, y = ty0 + py, x = tx0 + px;
+        const bool pok = n < p.B && y < p.H && x < p.W;
+        const size_t pix = (size_t)y * p.W + x;
+        // residual values first (all three forms reduced to one float4 per channel row here): their latency overlaps the
+        // transposition, and the store loop below is branch-free
+        float4 rv[8];
+        const bool with_res = p.ksplit == 1 && p.res != nullptr;
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int co = co0 + it * 4 + rsub;
+            rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (with_res && pok && co < p.Cout) {
+                const size_t plane = (size_t)n * p.Cout + co;
+                if (p.res_mode == 0) {
+                    rv[it] = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
+                } else if (p.res_mode == 1) {              // residual at half resolution, nearest up-sampling (unet.py:107)
+                    const int Hr = p.H >> 1, Wr = p.W >> 1;
+                    const float2 r2 = *reinterpret_cast<const float2*>(p.res + plane * (size_t)(Hr * Wr) + (size_t)(y >> 1) * Wr + (x >> 1));
+                    rv[it] = make_float4(r2.x, r2.x, r2.y, r2.y);
+                } else {                                   // residual at double resolution, 2x2 average pooling (unet.py:136)
+                    const int Wr = p.W * 2;
+                    const float* rp = p.res + plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
+                    const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
+                    const float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
+                    rv[it] = make_float4(((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f, ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f,
+                                         ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f, ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f);
+                }
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[q * 2 + jj][r] * p.out_scale;
+        // wave-private slab: program order + the compiler's lgkmcnt waits are all the synchronisation needed
+        const int slot = trem * GPI + (q % GPI);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int co_l = it * 4 + rsub;
+            const int co = co0 + co_l;
+            const bool cok = co < p.Cout;
+            float4 v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
+            if (!(cok && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (cok && pok) {
+                const size_t plane = (size_t)n * p.Cout + co;
+                if (p.ksplit == 1) {
+                    const float bv = p.bias[co];
+                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+                    v.x = rv[it].x + v.x; v.y = rv[it].y + v.y; v.z = rv[it].z + v.z; v.w = rv[it].w + v.w;
+                }
+                *reinterpret_cast<float4*>(dst + plane * HW + pix) = v;
+            }
+            if (do_stat) {
+                float s1 = (v.x + v.y) + (v.z + v.w);
+                float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                // inclusive scan over the 16-lane DPP row (row_shr 1, 2, 4, 8, zero fill): lane 15 of the row ends with the total
+                s1 += dpp_row_shr6<0x111>(s1); s2 += dpp_row_shr6<0x111>(s2);
+                s1 += dpp_row_shr6<0x112>(s1); s2 += dpp_row_shr6<0x112>(s2);
+                s1 += dpp_row_shr6<0x114>(s1); s2 += dpp_row_shr6<0x114>(s2);
+                s1 += dpp_row_shr6<0x118>(s1); s2 += dpp_row_shr6<0x118>(s2);
+                // a 64-pixel group belongs to ONE image (GPI groups per image and tile); groups wholly outside the image store 0
+                if (q4 == 15 && cok && n < p.B) p.stat[((size_t)n * p.Cout + co) * p.stat_slots + slot] = make_float2(s1, s2);
+            }
+        }
+    }
+#endif
+}
+
+// Deterministic split-K combine, one wave per (image, channel) plane: out = sum_s partial[s] (in order) + bias + residual,
+// and -- fused -- the fp64 GroupNorm statistics of the plane just written (the same {sum, sum of squares} record that
+// gn_stats_kernel produces), so split-K layers need no separate statistics pass.
+__global__ __launch_bounds__(256) void conv6_reduce_kernel(const float* partial, int ksplit, const float* bias, const float* res, int res_mode,
+                                                           float* out, int Cout, int H, int W, int planes, double2* stat) {
+    const int plane = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (plane >= planes) return;
+    const int HW = H * W;
+    const size_t total = (size_t)planes * HW;
+    const int co = plane % Cout;
+    const float bv = bias[co];
+    double s = 0.0, ss = 0.0;
+    for (int i4 = lane; i4 < (HW >> 2); i4 += 64) {
+        const size_t o = (size_t)plane * HW + (size_t)i4 * 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < ksplit; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(partial + (size_t)k * total + o);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        v.x += bv; v.y += bv; v.z += bv; v.w += bv;
+        if (res) {
+            const int r = i4 * 4;
+            const int y = r / W, x = r - y * W;
+            if (res_mode == 0) {
+                const float4 t = *reinterpret_cast<const float4*>(res + o);
+                v.x = t.x + v.x; v.y = t.y + v.y; v.z = t.z + v.z; v.w = t.w + v.w;
+            } else if (res_mode == 1) {
+                const int Hr = H >> 1, Wr = W >> 1;
+                const float2 t = *reinterpret_cast<const float2*>(res + (size_t)plane * (Hr * Wr) + (y >> 1) * Wr + (x >> 1));
+                v.x = t.x + v.x; v.y = t.x + v.y; v.z = t.y + v.z; v.w = t.y + v.w;
+            } else {
+                const int Wr = W * 2;
+                const float* rp = res + (size_t)plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
+                const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
+                const float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
+                v.x = ((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f + v.x;
+                v.y = ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f + v.y;
+                v.z = ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f + v.z;
+                v.w = ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f + v.w;
+            }
+        }
+        *reinterpret_cast<float4*>(out + o) = v;
+        s += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
+        ss += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    }
+    if (stat) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) { s += __shfl_xor(s, o, 64); ss += __shfl_xor(ss, o, 64); }
+        if (lane == 0) stat[plane] = make_double2(s, ss);
+    }
+}
+
+const float* conv_zero_page();
+
+static int conv6_geo(int H, int W) {
+    if ((W & 3) || W < 8 || H < 8) return -1;
+    return W >= 32 ? 0 : (W >= 16 ? 1 : 2);
+}
+bool conv6_supported(int H, int W) { return conv6_geo(H, W) >= 0; }
+
+// statistics slots per (image, channel) plane written by the epilogue when no split-K is used
+int conv6_stat_slots(int H, int W) {
+    const int g = conv6_geo(H, W);
+    if (g < 0) return 0;
+    const int tw = g == 0 ? 32 : (g == 1 ? 16 : 8), th = g == 0 ? 8 : (g == 1 ? 16 : 8);
+    return ((W + tw - 1) / tw) * ((H + th - 1) / th) * ((tw * th) / 64);
+}
+
+template <int GEO, int R>
+static Status launch6(hipStream_t s, Conv6K k, int blocks) {
+    using G = Geo6<GEO>;
+    constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;
+    constexpr size_t LDS = (size_t)4 * NPIECE * 1024 + (size_t)4 * R * 2048;
+    static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
+    auto fn = conv6_mfma_kernel<GEO, R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), LDS, s, k);
+    return Status{};
+}
+
+// stat_kind_out: 0 none, 1 epilogue slots (a.stat filled, conv6_stat_slots entries per plane), 2 per-plane fp64 records (a.stat_plane)
+Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out) {
+    if (stat_kind_out) *stat_kind_out = 0;
+    const int geo = conv6_geo(a.H, a.W);
+    if (geo < 0) return Status{DPIR_ERR_UNSUPPORTED, "conv6: shape not tiled"};
+    Conv6K k;
+    k.xhi = reinterpret_cast<const char*>(a.xhi); k.xlo = reinterpret_cast<const char*>(a.xlo);
+    k.w16 = reinterpret_cast<const char*>(a.w16); k.bias = a.bias; k.out = a.out; k.res = a.res; k.res_mode = a.res_mode;
+    k.B = a.B; k.Cout = a.Cout; k.H = a.H; k.W = a.W;
+    k.n_chunks_total = (a.Cin + 15) / 16;
+    k.C8 = 2 * k.n_chunks_total;          // act.hip pads the blocked tensor to whole 16-channel chunks
+    k.partial = a.partial; k.ksplit = 1; k.chunks_per_split = 0;
+    k.out_scale = 1.0f / a.w16_scale;
+    k.zeros = conv_zero_page();
+    if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv6: cannot allocate the zero page"};
+    const int tw = geo == 0 ? 32 : (geo == 1 ? 16 : 8), th = geo == 0 ? 8 : (geo == 1 ? 16 : 8), ti = geo == 2 ? 4 : 1;
+    k.tiles_x = (a.W + tw - 1) / tw;
+    k.tiles_y = (a.H + th - 1) / th;
+    const int n_ptiles = k.tiles_x * k.tiles_y * ((a.B + ti - 1) / ti);
+    k.n_co_blocks = (a.Cout + 127) / 128;
+    const int chunks = k.n_chunks_total;
+    const int blocks = n_ptiles * k.n_co_blocks;
+    // split-K when the launch cannot give every CU its two workgroups (low-resolution layers); deterministic slabs
+    int S = 1;
+    if (k.partial && blocks < 384) {
+        S = (512 + blocks - 1) / blocks;
+        if (S > chunks / 2) S = chunks / 2;
+        if (S > 16) S = 16;
+        if (S < 1) S = 1;
+        if ((size_t)S * k.B * k.Cout * k.H * k.W > a.partial_capacity) S = 1;
+    }
+    k.chunks_per_split = (chunks + S - 1) / S;
+    S = (chunks + k.chunks_per_split - 1) / k.chunks_per_split;      // no empty slice: every workgroup owns at least one chunk
+    k.ksplit = S;
+    if (S == 1) k.partial = nullptr;
+    k.stat = nullptr; k.stat_slots = 0;
+    if (a.stat && S == 1) {
+        k.stat = a.stat; k.stat_slots = conv6_stat_slots(a.H, a.W);
+        if (stat_kind_out) *stat_kind_out = 1;
+    }
+    if (geo == 0) DPIR_TRY((launch6<0, 4>(s, k, blocks * S)));
+    else if (geo == 1) DPIR_TRY((launch6<1, 4>(s, k, blocks * S)));
+    else DPIR_TRY((launch6<2, 3>(s, k, blocks * S)));
+    if (S > 1) {
+        const int planes = k.B * k.Cout;
+        hipLaunchKernelGGL(conv6_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, k.partial, S, k.bias, k.res, k.res_mode, k.out,
+                           k.Cout, k.H, k.W, planes, a.stat_plane);
+        if (a.stat_plane && stat_kind_out) *stat_kind_out = 2;
+    }
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+// Host: OIHW fp32 -> [chunk (16 ci)][co-block (128)][wave (32 co)][tap][hi|lo][k-half][32 co][8 ci] f16: one 2 KiB record per
+// (wave, tap), its two 1 KiB halves in MFMA A-fragment lane order (lane = k-half * 32 + co).  Scaled by a power of two so
+// that max|w| * scale is in [512, 1024) (keeps the low halves out of the f16 subnormal range); returns the scale.
+float pack_weights_conv6(const float* w, int cout, int cin, std::vector<uint16_t>& out) {
+    const int taps = 9;
+    const int chunks = (cin + 15) / 16, cblocks = (cout + 127) / 128;
+    float mx = 0.f;
+    for (size_t i = 0; i < (size_t)cout * cin * taps; ++i) mx = fmaxf(mx, fabsf(w[i]));
+    float scale = 1.0f;
+    if (mx > 0.f) scale = exp2f(floorf(log2f(1024.0f / mx)));
+    while (mx * scale >= 1024.0f) scale *= 0.5f;
+    out.assign((size_t)chunks * cblocks * 4 * taps * 1024, 0);       // 1024 halves = 2 KiB per record
+    for (int ch = 0; ch < chunks; ++ch)
+        for (int cbk = 0; cbk < cblocks; ++cbk)
+            for (int wv = 0; wv < 4; ++wv)
+                for (int tap = 0; tap < taps; ++tap) {
+                    uint16_t* hi = out.data() + ((((size_t)ch * cblocks + cbk) * 4 + wv) * taps + tap) * 1024;
+                    uint16_t* lo = hi + 512;
+                    for (int kh = 0; kh < 2; ++kh)
+                        for (int col = 0; col < 32; ++col)
+                            for (int j = 0; j < 8; ++j) {
+                                const int co = cbk * 128 + wv * 32 + col, ci = ch * 16 + kh * 8 + j;
+                                const float v = (co < cout && ci < cin) ? w[((size_t)co * cin + ci) * taps + tap] * scale : 0.f;
+                                const _Float16 h = (_Float16)v;
+                                const _Float16 l = (_Float16)(v - (float)h);
+                                const size_t o = ((size_t)kh * 32 + col) * 8 + j;
+                                __builtin_memcpy(&hi[o], &h, 2);
+                                __builtin_memcpy(&lo[o], &l, 2);
+                            }
+                }
+    return scale;
+}
+
+}  // namespace dpir

@@ -88,6 +88,14 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
         e->net.allocs.push_back(p);
         DPIR_HIP(hipMemcpy(p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
         out->w16 = p;
+        if (ks == 3) {
+            out->w16b_scale = pack_weights_conv6(w, cout, cin, w16);
+            void* q = nullptr;
+            if (hipMalloc(&q, w16.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for split weights failed"};
+            e->net.allocs.push_back(q);
+            DPIR_HIP(hipMemcpy(q, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
+            out->w16b = q;
+        }
     }
     return Status{};
 }
@@ -274,10 +282,46 @@ struct Fwd {
     float* partial;        // split-K slab shared by all convolutions of the forward
     size_t partial_cap;
     // GroupNorm statistics already produced by the epilogue of the convolution that wrote a tensor (keyed by its address)
-    struct FusedStat { const float2* slots; int nslots; };
+    struct FusedStat { const float2* slots; int nslots; const double2* part; };   // epilogue slots, or per-plane fp64 records (split-K combine)
     std::unordered_map<const float*, FusedStat> fused;
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
+        if (cw.w16b && cw.ks == 3 && e->conv_impl == 6 && conv6_supported(Ho, Wo)) {
+            // operand-split f16 path, current generation: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
+            // then conv6 (pure LDS-DMA + MFMA, two workgroups per CU); GroupNorm statistics of the output come out of its
+            // epilogue or of its split-K combine
+            int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
+            if (eh != in.H || ew != in.W) return invalid("conv: source resolution does not match mode");
+            const int C = in.C(), C8 = 2 * ((C + 15) / 16);
+            const size_t plane = (size_t)B * C8 * Ho * Wo * 16;
+            if (plane >= ((size_t)1 << 32)) return invalid("conv: split activation plane exceeds the 4 GiB buffer-descriptor range; reduce the batch");
+            char* s16 = nullptr;
+            DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
+            {
+                ProfScope ps(&e->prof, PC_ELEM);
+                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane, e->range_ctr));
+            }
+            Conv6Args a6;
+            a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16b; a6.w16_scale = cw.w16b_scale;
+            a6.bias = cw.bias; a6.out = out; a6.res = res; a6.res_mode = res_mode;
+            a6.B = B; a6.Cin = cw.cin; a6.Cout = cw.cout; a6.H = Ho; a6.W = Wo;
+            a6.partial = partial; a6.partial_capacity = partial_cap;
+            const int slots = conv6_stat_slots(Ho, Wo);
+            float2* st = nullptr; double2* sp = nullptr;
+            if (slots > 0 && cw.cout % 32 == 0) {
+                const std::string key = std::to_string(reinterpret_cast<uintptr_t>(out));
+                DPIR_TRY(ws.getT("st#" + key, (size_t)B * cw.cout * slots, &st));
+                DPIR_TRY(ws.getT("sp#" + key, (size_t)B * cw.cout, &sp));
+            }
+            a6.stat = st; a6.stat_plane = sp;
+            int kind = 0;
+            ProfScope ps(&e->prof, PC_CONV3);
+            DPIR_TRY(launch_conv6(s, a6, &kind));
+            if (kind == 1) fused[out] = FusedStat{st, slots, nullptr};
+            else if (kind == 2) fused[out] = FusedStat{nullptr, 0, sp};
+            else fused.erase(out);
+            return Status{};
+        }
         if (cw.w16 && cw.ks == 3 && conv4_supported(Ho, Wo)) {
             // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split), then a
             // convolution that is pure LDS-DMA + MFMA
@@ -303,7 +347,7 @@ struct Fwd {
             bool wrote = false;
             ProfScope ps(&e->prof, PC_CONV3);
             DPIR_TRY(launch_conv4(s, a4, &wrote));
-            if (wrote) fused[out] = FusedStat{st, slots}; else fused.erase(out);
+            if (wrote) fused[out] = FusedStat{st, slots, nullptr}; else fused.erase(out);
             return Status{};
         }
         if (cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo)) {
@@ -335,7 +379,7 @@ struct Fwd {
             src[k].c = tc[k];
             if (!tp[k] || tc[k] == 0) { src[k].c = 0; continue; }
             auto it = fused.find(tp[k]);
-            if (it != fused.end()) { src[k].slots = it->second.slots; src[k].nslots = it->second.nslots; continue; }
+            if (it != fused.end()) { src[k].slots = it->second.slots; src[k].nslots = it->second.nslots; src[k].part = it->second.part; continue; }
             double2* part = nullptr;     // this tensor was not written by a statistics-fusing kernel: one streaming pass
             DPIR_TRY(ws.getT(tag + "#stats" + std::to_string(k), (size_t)B * tc[k], &part));
             ProfScope ps(&e->prof, PC_GN);
