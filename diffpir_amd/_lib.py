@@ -42,6 +42,11 @@ class LoopDesc(C.Structure):
                 ("noise_rp_dev", C.c_void_p)]
 
 
+class DegradeDesc(C.Structure):
+    _fields_ = [("task", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("sf", C.c_int32),
+                ("kh", C.c_int32), ("kw", C.c_int32), ("noise_level_img", C.c_float), ("seed", C.c_uint64), ("image_offset", C.c_int64)]
+
+
 PROF_CLASSES = 8
 PROF_NAMES = ["conv3x3", "conv1x1", "groupnorm_stats", "attention", "fft_prox", "elementwise", "unet_forward", "loop_graph"]
 
@@ -78,6 +83,8 @@ SIGNATURES = {
     "dpir_repaint_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_degrade": (C.c_int, [C.c_void_p, C.POINTER(DegradeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "dpir_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dpir_run_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.c_int, C.c_void_p, C.c_void_p]),
     "dpir_prof_enable": (C.c_int, [C.c_void_p, C.c_int]),
     "dpir_prof_reset": (C.c_int, [C.c_void_p]),

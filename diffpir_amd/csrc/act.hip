@@ -69,7 +69,7 @@ __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4
     }
     const size_t o = (((size_t)n * C8 + c8) * HW + pix) * 8;
     *reinterpret_cast<half8*>(hi + o) = h8;
-    *reinterpret_cast<half8*>(lo + o) = l8;
+    if (lo) *reinterpret_cast<half8*>(lo + o) = l8;
     range_report(bad, range_ctr);
 }
 
@@ -134,7 +134,7 @@ __global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float
         if (e < rem) {
             const int sl = (e & 3) * PS + (e >> 2);
             gh[e] = sh_hi[sl];
-            gl[e] = sh_lo[sl];
+            if (lo) gl[e] = sh_lo[sl];
         }
     }
 }

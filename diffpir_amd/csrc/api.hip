@@ -29,7 +29,7 @@ static void prox_release(dpir::ProxState* st);
 // f16x3 operand range guard: called where the ABI synchronises anyway (dpir_sync, D2H copies).  A non-zero count means
 // at least that many wave-lanes clamped an activation to the f16 range since the last check: the images are wrong.
 static int check_range(dpir_engine* e) {
-    if (!e->range_ctr || e->precision != 1) return DPIR_OK;
+    if (!e->range_ctr || e->precision == 0) return DPIR_OK;
     unsigned long long n = 0;
     if (hipMemcpyAsync(&n, e->range_ctr, sizeof(n), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
@@ -208,7 +208,7 @@ static Status upload_ints(dpir_engine* e, const char* name, const int64_t* host,
 
 int dpir_set_precision(dpir_engine* e, int mode) {
     if (!e) return DPIR_ERR_INVALID;
-    if (mode != 0 && mode != 1) return fail(e, invalid("dpir_set_precision: mode must be 0 (fp32 MFMA) or 1 (operand-split f16x3 MFMA)"));
+    if (mode < 0 || mode > 2) return fail(e, invalid("dpir_set_precision: mode must be 0 (fp32 MFMA), 1 (operand-split f16x3 MFMA) or 2 (f16x1: f16 operands, fp32 accumulate)"));
     if (e->net.loaded && mode != e->precision) return fail(e, Status{DPIR_ERR_STATE, "dpir_set_precision must be called before dpir_load_unet"});
     e->precision = mode;
     return DPIR_OK;
@@ -501,6 +501,62 @@ int dpir_randn(dpir_engine* e, float* out, uint64_t seed, uint64_t stream_id, in
     if (!e || !out) return fail(e, invalid("dpir_randn: null argument"));
     ProfScope ps(&e->prof, PC_ELEM);
     API_TRY(e, launch_randn(e->stream, out, seed, stream_id, image_offset, B, (size_t)C * H * W));
+    return DPIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ degradation + metrics
+int dpir_degrade(dpir_engine* e, const dpir_degrade_desc* d, const uint8_t* gt, const float* k, const uint8_t* mask, const float* noise, float* y) {
+    if (!e || !d || !gt || !y) return fail(e, invalid("dpir_degrade: null argument"));
+    (void)hipSetDevice(e->device);
+    const int B = d->B, H = d->H, W = d->W, sf = d->sf < 1 ? 1 : d->sf;
+    if (B <= 0 || H <= 0 || W <= 0 || H % sf || W % sf) return fail(e, invalid("dpir_degrade: bad shape"));
+    hipStream_t s = e->stream;
+    ProfScope ps(&e->prof, PC_ELEM);
+    const int h = H / sf, w = W / sf;
+    if (d->task == DPIR_TASK_DEBLUR) {
+        if (!k) return fail(e, invalid("dpir_degrade: deblurring needs a PSF"));
+        API_TRY(e, launch_blur_wrap_u8(s, gt, k, d->kh, d->kw, B, H, W, y));
+    } else if (d->task == DPIR_TASK_INPAINT) {
+        if (!mask) return fail(e, invalid("dpir_degrade: inpainting needs a mask"));      // img_H * mask / 255 is formed in the finish kernel (float64)
+    } else if (d->task == DPIR_TASK_SR_BLUR || d->task == DPIR_TASK_SR_CUBIC) {
+        float* full = nullptr;
+        API_TRY(e, e->ws.getT("degrade#full", (size_t)B * 3 * H * W, &full));
+        API_TRY(e, launch_u8_to_single(s, gt, nullptr, B, H * W, full));
+        API_TRY(e, resize_down_impl(e, full, 1.f, 0.f, y, sf, B, H, W));
+    } else return fail(e, invalid("dpir_degrade: unknown task"));
+    const size_t total = (size_t)B * 3 * h * w;
+    const float* nz = noise;
+    if (!nz && d->noise_level_img != 0.f) {
+        float* nb = nullptr;
+        API_TRY(e, e->ws.getT("degrade#noise", total, &nb));
+        API_TRY(e, launch_randn(s, nb, d->seed, 7, d->image_offset, B, (size_t)3 * h * w));      // Philox stream 7: outside the loop's 0..3 + 4i
+        nz = nb;
+    }
+    const bool inp = d->task == DPIR_TASK_INPAINT;
+    API_TRY(e, launch_degrade_finish(s, y, d->noise_level_img != 0.f ? nz : nullptr, (double)d->noise_level_img * 2.0,
+                                     inp ? mask : nullptr, inp ? gt : nullptr, H * W, total));
+    return DPIR_OK;
+}
+
+int dpir_metrics(dpir_engine* e, const float* x0, const uint8_t* gt, int B, int H, int W, float* psnr_host, float* psnr_y_host) {
+    if (!e || !x0 || !gt || !psnr_host || B <= 0) return fail(e, invalid("dpir_metrics: null argument"));
+    (void)hipSetDevice(e->device);
+    double2* acc = nullptr;
+    API_TRY(e, e->ws.getT("metrics#acc", (size_t)B, &acc));
+    {
+        ProfScope ps(&e->prof, PC_ELEM);
+        API_TRY(e, launch_metrics(e->stream, x0, gt, B, H * W, acc));
+    }
+    std::vector<double2> h(B);
+    int rc = dpir_d2h(e, h.data(), acc, sizeof(double2) * B);
+    if (rc != DPIR_OK) return rc;
+    const float cnt = (float)(3.0 * H * W);
+    for (int i = 0; i < B; ++i) {
+        // utils_image.calculate_psnr_batch in float32: inf when mse == 0, else 20*log10(max_pixel / sqrt(mse + eps))
+        const float mse = (float)(h[i].x / (double)cnt), mse_y = (float)(h[i].y / (double)cnt);
+        psnr_host[i] = mse == 0.f ? INFINITY : 20.0f * log10f(2.0f / sqrtf(mse + 1e-10f));
+        if (psnr_y_host) psnr_y_host[i] = mse_y == 0.f ? INFINITY : 20.0f * log10f(2.0f / sqrtf(mse_y + 1e-10f));
+    }
     return DPIR_OK;
 }
 

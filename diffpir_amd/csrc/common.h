@@ -118,6 +118,7 @@ struct CatSrc { const float* a; int ca; const float* b; int cb; };
 // act.hip + conv4.hip: operand-split f16 path with a separate activation pre-pass
 // hi / lo: blocked [B][C8][H][W][8] f16 planes, C8 = 2*ceil(C/16); mode: 0 plain, 1 nearest-up source, 2 avg-pool source
 // range_ctr: device counter of operand values outside the f16 range (see act.hip range_report), or null
+// lo == nullptr: single-product mode, only the hi plane is produced
 Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo,
                         unsigned long long* range_ctr = nullptr);
 struct Conv4Args {
@@ -140,6 +141,7 @@ struct Conv6Args {
     float* partial = nullptr; size_t partial_capacity = 0;
     float2* stat = nullptr;        // optional [B][Cout][conv6_stat_slots(H, W)] epilogue partial sums (no split-K)
     double2* stat_plane = nullptr; // optional [B][Cout] fp64 {sum, sum of squares}, written by the split-K combine
+    bool x1 = false;               // single-product mode (f16x1): hi planes / hi weight halves only
 };
 bool conv6_supported(int H, int W);
 int conv6_stat_slots(int H, int W);
@@ -152,6 +154,7 @@ struct Conv5Args {
     const float* bias = nullptr; float* out = nullptr; const float* res = nullptr;   // res: same shape as out, or null
     int B = 0, Cout = 0, H = 0, W = 0;
     unsigned long long* range_ctr = nullptr;   // f16 operand range guard (act.hip range_report)
+    bool x1 = false;                           // single-product mode (f16x1)
 };
 bool conv5_supported(int B, int Cout, int H, int W);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);

@@ -29,7 +29,7 @@ struct Conv5K {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <bool HAS_PRM>
+template <bool HAS_PRM, bool X1>
 __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
     constexpr int WCO = 4, WPX = 2;
     constexpr int XBYTES = 16 * 1024;        // [16 ch][256 px] fp32
@@ -125,22 +125,24 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
                 float x = fminf(fmaxf(v[jj], -65000.f), 65000.f);
                 _Float16 hh = (_Float16)x;
                 bh[j][jj] = hh;
-                bl[j][jj] = (_Float16)(x - (float)hh);
+                if (!X1) bl[j][jj] = (_Float16)(x - (float)hh);
             }
         }
         half8 ah[WCO], al[WCO];
 #pragma unroll
-        for (int i = 0; i < WCO; ++i) { ah[i] = wh[i * 32]; al[i] = wl[i * 32]; }
+        for (int i = 0; i < WCO; ++i) { ah[i] = wh[i * 32]; if (!X1) al[i] = wl[i * 32]; }
+        if (!X1) {
 #pragma unroll
-        for (int i = 0; i < WCO; ++i)
+            for (int i = 0; i < WCO; ++i)
 #pragma unroll
-            for (int j = 0; j < WPX; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WPX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], acc[i][j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < WCO; ++i)
+            for (int i = 0; i < WCO; ++i)
 #pragma unroll
-            for (int j = 0; j < WPX; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < WPX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+        }
 #pragma unroll
         for (int i = 0; i < WCO; ++i)
 #pragma unroll
@@ -199,8 +201,11 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a) {
     k.out_scale = 1.0f / a.w16_scale;
     k.range_ctr = a.range_ctr;
     const unsigned blocks = (unsigned)(((k.total_px + 255) / 256) * k.n_co_blocks);
-    if (a.prm) hipLaunchKernelGGL(conv5_mfma_kernel<true>, dim3(blocks), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(conv5_mfma_kernel<false>, dim3(blocks), dim3(256), 0, s, k);
+    if (a.x1) {
+        if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, true>), dim3(blocks), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((conv5_mfma_kernel<false, true>), dim3(blocks), dim3(256), 0, s, k);
+    } else if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, false>), dim3(blocks), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((conv5_mfma_kernel<false, false>), dim3(blocks), dim3(256), 0, s, k);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -90,19 +90,22 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 // DMA instructions issued by the group of tap i of a chunk (i < 0: tap i + 9 of the previous chunk, always a MORE body):
 // [one activation piece of the next chunk if i < nact] + [the two weight pieces of tap i + d]
-constexpr int c6_gsize(bool more, int nact, int d, int i) {
+// wp: weight pieces per tap (2 = hi + lo; 1 in the single-product f16x1 mode)
+constexpr int c6_gsize(bool more, int nact, int d, int i, int wp) {
     const int j = i < 0 ? i + 9 : i;
     const bool m = i < 0 ? true : more;
-    return ((m && j < nact) ? 1 : 0) + ((m || j + d < 9) ? 2 : 0);
+    return ((m && j < nact) ? 1 : 0) + ((m || j + d < 9) ? wp : 0);
 }
 // number of DMA instructions issued AFTER the weights of tap + 1 at the point where they are read (after the group of `tap`)
-constexpr int c6_wait_n(bool more, int nact, int d, int tap) {
+constexpr int c6_wait_n(bool more, int nact, int d, int tap, int wp) {
     int s = 0;
-    for (int i = tap + 2 - d; i <= tap; ++i) s += c6_gsize(more, nact, d, i);
+    for (int i = tap + 2 - d; i <= tap; ++i) s += c6_gsize(more, nact, d, i, wp);
     return s;
 }
 
-template <int GEO, int R>
+// X1: single-product mode (f16x1): only the hi halves of both operands exist / are moved / are multiplied -- f16 operands with
+// fp32 accumulation, the reference's own fp16 recipe (fp16_util.py:15-32, unet.py:618-632) -- one MFMA per product.
+template <int GEO, int R, bool X1>
 __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     // The body uses the buffer-descriptor builtin type, which only exists in the DEVICE pass of hipcc; in the host pass an
     // (ill-formed) template body would silently drop the kernel's launch stub, so the host pass sees an empty body.
@@ -113,7 +116,8 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     constexpr int PATCH = TI * LH * LW;                 // patch positions = entries per k-half
     constexpr int NPIECE = (2 * PATCH + 63) / 64;       // 1 KiB DMA pieces per plane (hi or lo)
     constexpr int NXT = (NPIECE + 3) / 4;               // pieces per wave per plane
-    constexpr int NACT = 2 * NXT;                       // activation DMA instructions per wave per chunk
+    constexpr int NPL = X1 ? 1 : 2;                     // operand planes (hi [, lo])
+    constexpr int NACT = NPL * NXT;                     // activation DMA instructions per wave per chunk
     constexpr int XB = NPIECE * 1024;                   // bytes per plane buffer
     constexpr int D = R - 1;                            // weight prefetch distance in taps
     constexpr int TAPS = 9;
@@ -144,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     const int tx0 = (trem % p.tiles_x) * TW;
     const int n0 = img_grp * TI;
     const int HW = p.H * p.W;
-    const bool wave_live = co0 < p.Cout;                // waves beyond Cout multiply zero-padded weights and store nothing
+    const bool wave_live = co0 < p.Cout;
 
     // ---- per-lane DMA source offsets of this wave's activation pieces (chunk invariant, BYTES from the first entry of the
     // chunk's first channel group); out-of-image positions get kOutOfRange (hardware zero fill).
@@ -192,19 +196,37 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
         const __amdgpu_buffer_rsrc_t rw = rsrc_uniform(wsrc0 + (size_t)chunk_rel * wchunk_stride, TAPS * 2048);
         char* dst = ring + slot * 2048;
         BLDS6(rw, dst, lane16, tap * 2048);
-        BLDS6(rw, dst + 1024, lane16, tap * 2048 + 1024);
+        if (!X1) BLDS6(rw, dst + 1024, lane16, tap * 2048 + 1024);
     };
     // activation piece q (0 .. NACT-1: u = q / 2, plane = q & 1) of chunk `chunk` -> buffer buf.  One chunk = two channel groups
     // of HW entries; the descriptor base moves with the chunk, num_records = the plane (valid offsets never leave it).
     const size_t xplane_bytes = (size_t)p.B * p.C8 * HW * 16;
     auto dma_x = [&](int chunk, int buf, int q) __attribute__((always_inline)) {
-        const int u = q >> 1, plane = q & 1;
+        const int u = X1 ? q : q >> 1, plane = X1 ? 0 : q & 1;
         int piece = wave + u * 4;
         if (piece > NPIECE - 1) piece = NPIECE - 1;
         const size_t coff = (size_t)chunk * 2 * HW * 16;
         const __amdgpu_buffer_rsrc_t rx = rsrc_uniform((plane ? p.xlo : p.xhi) + coff, (unsigned)(xplane_bytes - coff));
         BLDS6(rx, lds_x + buf * 2 * XB + plane * XB + piece * 1024, x_off[u], 0);
     };
+
+    // Waves whose 32 output channels lie beyond Cout (Cout = 6 of the output layer: three of four waves) only carry their share
+    // of the activation DMA and keep the barrier count: prologue, one per chunk boundary, epilogue.  No weights, no MFMAs.
+    if (!wave_live) {
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+        wait_vmcnt<0>();
+        __syncthreads();
+        int it = 0;
+        for (int chunk = ch_begin; chunk + 1 < ch_end; ++chunk, ++it) {
+#pragma unroll
+            for (int q = 0; q < NACT; ++q) dma_x(chunk + 1, (it & 1) ^ 1, q);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        __syncthreads();
+        return;
+    }
 
     // ---- prologue: the first chunk's patch and the first D taps of weights, all waited for
 #pragma unroll
@@ -220,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     auto read_a = [&](int slot, int rs) __attribute__((always_inline)) {
         const half8* w = abase + slot * 128;           // 2048 B per slot = 128 entries
         a_h[rs] = w[0];
-        a_l[rs] = w[64];
+        if (!X1) a_l[rs] = w[64];
     };
     auto read_b = [&](int buf, int tap, int grp, int set) __attribute__((always_inline)) {      // pixel tiles 2 grp, 2 grp + 1
         const half8* xh = xbase + buf * (2 * XB / 16);
@@ -230,15 +252,17 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
         for (int j = 0; j < 2; ++j) {
             const int o = tile_off(grp * 2 + j) + toff;
             b_h[set][j] = xh[o];
-            b_l[set][j] = xl[o];
+            if (!X1) b_l[set][j] = xl[o];
         }
     };
     auto mfma_group = [&](int grp, int set, int rs) __attribute__((always_inline)) {
         // the three partial products of one accumulator are issued two MFMAs apart; small terms first
+        if (!X1) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[rs], b_h[set][j], acc[grp * 2 + j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[rs], b_h[set][j], acc[grp * 2 + j], 0, 0, 0);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[rs], b_l[set][j], acc[grp * 2 + j], 0, 0, 0);
+            for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[rs], b_l[set][j], acc[grp * 2 + j], 0, 0, 0);
+        }
 #pragma unroll
         for (int j = 0; j < 2; ++j) acc[grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[rs], b_h[set][j], acc[grp * 2 + j], 0, 0, 0);
     };
@@ -277,7 +301,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
             mfma_group(2, 0, rs);
             __builtin_amdgcn_sched_barrier(0);
             if (tap + 1 < TAPS) {
-                wait_vmcnt<c6_wait_n(MORE, NACT, D, tap)>();
+                wait_vmcnt<c6_wait_n(MORE, NACT, D, tap, NPL)>();
                 read_a((rbase + tap + 1) % R, (tap + 1) & 1);
                 read_b(cur, tap + 1, 0, 0);
             } else if (MORE) {
@@ -286,9 +310,9 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
                 // then says every wave is done reading the current patch and writing / receiving the next one.  After it: the
                 // weights of the next chunk's tap 0 (followed by the groups of taps 11-D .. 8) -- an EXPLICIT wait: the compiler
                 // does not know that a ds_read depends on an LDS-DMA and may leave vmcnt out of the barrier's wait.
-                wait_vmcnt<2 + 2 * (TAPS - NACT)>();
+                wait_vmcnt<NPL + NPL * (TAPS - NACT)>();
                 __syncthreads();
-                wait_vmcnt<c6_wait_n(true, NACT, D, TAPS - 1)>();
+                wait_vmcnt<c6_wait_n(true, NACT, D, TAPS - 1, NPL)>();
                 read_a((rbase + TAPS) % R, 1);
                 read_b(cur ^ 1, 0, 0, 0);
             }
@@ -296,7 +320,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
             mfma_group(3, 1, rs);
             __builtin_amdgcn_sched_barrier(0);
         });
-        if (MORE) { a_h[0] = a_h[1]; a_l[0] = a_l[1]; }     // 9 taps: the next chunk's tap 0 uses register set 0 again
+        if (MORE) { a_h[0] = a_h[1]; if (!X1) a_l[0] = a_l[1]; }     // 9 taps: the next chunk's tap 0 uses register set 0 again
     };
     {   // all chunks but the last in a loop with ONE body (a branch between two bodies inside the loop keeps the register
         // coalescer from unifying the accumulators across the back edge: two live copies of 128 registers), then the last
@@ -311,7 +335,6 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     __syncthreads();                                         // all waves are done with the operand buffers
     constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
     float* tr = reinterpret_cast<float*>(smem6) + wave * (32 * TS);
-    if (!wave_live) return;
     const int q4 = lane & 15, rsub = lane >> 4;
     float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
     const bool do_stat = p.stat != nullptr && p.ksplit == 1;
@@ -458,14 +481,14 @@ int conv6_stat_slots(int H, int W) {
     return ((W + tw - 1) / tw) * ((H + th - 1) / th) * ((tw * th) / 64);
 }
 
-template <int GEO, int R>
+template <int GEO, int R, bool X1>
 static Status launch6(hipStream_t s, Conv6K k, int blocks) {
     using G = Geo6<GEO>;
     constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
     constexpr int NPIECE = (2 * PATCH + 63) / 64;
     constexpr size_t LDS = (size_t)4 * NPIECE * 1024 + (size_t)4 * R * 2048;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
-    auto fn = conv6_mfma_kernel<GEO, R>;
+    auto fn = conv6_mfma_kernel<GEO, R, X1>;
     static bool attr_set = false;
     if (!attr_set) {
         DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
@@ -515,9 +538,13 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out) {
         k.stat = a.stat; k.stat_slots = conv6_stat_slots(a.H, a.W);
         if (stat_kind_out) *stat_kind_out = 1;
     }
-    if (geo == 0) DPIR_TRY((launch6<0, 4>(s, k, blocks * S)));
-    else if (geo == 1) DPIR_TRY((launch6<1, 4>(s, k, blocks * S)));
-    else DPIR_TRY((launch6<2, 3>(s, k, blocks * S)));
+    if (a.x1) {
+        if (geo == 0) DPIR_TRY((launch6<0, 4, true>(s, k, blocks * S)));
+        else if (geo == 1) DPIR_TRY((launch6<1, 4, true>(s, k, blocks * S)));
+        else DPIR_TRY((launch6<2, 3, true>(s, k, blocks * S)));
+    } else if (geo == 0) DPIR_TRY((launch6<0, 4, false>(s, k, blocks * S)));
+    else if (geo == 1) DPIR_TRY((launch6<1, 4, false>(s, k, blocks * S)));
+    else DPIR_TRY((launch6<2, 3, false>(s, k, blocks * S)));
     if (S > 1) {
         const int planes = k.B * k.Cout;
         hipLaunchKernelGGL(conv6_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, k.partial, S, k.bias, k.res, k.res_mode, k.out,

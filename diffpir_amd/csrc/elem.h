@@ -41,6 +41,11 @@ Status launch_ibp_update(hipStream_t s, float* x0, const float* y, const float* 
 Status launch_bicubic_up(hipStream_t s, const float* in, float* out, int P, int h, int w, int sf);
 Status launch_randn(hipStream_t s, float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, int B, size_t per_image,
                     const StepDev* sp = nullptr, const LoopDev* lp = nullptr);   // sp: stream_id += 4 * sp->i; lp: seed / image_offset from the device block
+// degrade.hip: degradation synthesis on the uint8 ground truth and per-image metric sums
+Status launch_blur_wrap_u8(hipStream_t s, const uint8_t* gt, const float* k, int kh, int kw, int B, int H, int W, float* out);
+Status launch_u8_to_single(hipStream_t s, const uint8_t* gt, const uint8_t* mask, int B, int HW, float* out);
+Status launch_degrade_finish(hipStream_t s, float* y, const float* noise, double sigma2, const uint8_t* mask, const uint8_t* gt, int HW, size_t total);
+Status launch_metrics(hipStream_t s, const float* x0, const uint8_t* gt, int B, int HW, double2* out);
 void resizer_band(int in_len, int out_len, double scale, std::vector<float>& w_out, std::vector<int>& idx_out, int& taps_out);
 
 // fft.hip ------------------------------------------------------------------------------------

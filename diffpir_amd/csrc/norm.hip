@@ -150,9 +150,37 @@ __global__ __launch_bounds__(256) void rows_gemv_kernel(const float* W, const fl
     }
 }
 
+// out[n, r] = dot(W[r,:], x[n,:]) + bias[r] for ALL n: one wave per weight row (the row is read from HBM/L2 once, kept in
+// registers for K <= 1024, and dotted with every image's vector, which stays in L1/L2)
+__global__ __launch_bounds__(256) void rows_gemv_all_kernel(const float* W, const float* bias, const float* x, int B, int R, int K, float* out) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (r >= R) return;
+    const float* wr = W + (size_t)r * K;
+    float w[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) w[i] = lane + 64 * i < K ? wr[lane + 64 * i] : 0.f;
+    const float bv = bias[r];
+    for (int n = 0; n < B; ++n) {
+        const float* xn = x + (size_t)n * K;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (lane + 64 * i < K) acc = fmaf(w[i], xn[lane + 64 * i], acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) out[(size_t)n * R + r] = acc + bv;
+    }
+}
+
 Status launch_rows_gemv(hipStream_t s, const float* W, const float* bias, const float* x, int B, int R, int K, float* out) {
-    hipLaunchKernelGGL(rows_gemv_kernel<0>, dim3((R + 3) / 4, B), dim3(256), 0, s, W, bias, x, R, K, out,
-                       (const float*)nullptr, (const int*)nullptr);
+    if (K <= 1024) {
+        // same per-lane summation order as rows_gemv_kernel (k = lane, lane + 64, ...), so results are bit-identical
+        hipLaunchKernelGGL(rows_gemv_all_kernel, dim3((R + 3) / 4), dim3(256), 0, s, W, bias, x, B, R, K, out);
+    } else {
+        hipLaunchKernelGGL(rows_gemv_kernel<0>, dim3((R + 3) / 4, B), dim3(256), 0, s, W, bias, x, R, K, out,
+                           (const float*)nullptr, (const int*)nullptr);
+    }
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -80,7 +80,7 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
     DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
     DPIR_TRY(upload(e, b, cout, &out->bias));
-    if (e->precision == 1 && (ks == 3 || ks == 1)) {
+    if (e->precision >= 1 && (ks == 3 || ks == 1)) {
         std::vector<uint16_t> w16;
         out->w16_scale = ks == 3 ? pack_weights_f16x3(w, cout, cin, ks, w16) : pack_weights_f16x3_1x1(w, cout, cin, w16);
         void* p = nullptr;
@@ -286,7 +286,8 @@ struct Fwd {
     std::unordered_map<const float*, FusedStat> fused;
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
-        if (cw.w16b && cw.ks == 3 && e->conv_impl == 6 && conv6_supported(Ho, Wo)) {
+        const bool x1 = e->precision == 2;        // f16x1: single-product mode, hi halves only
+        if (cw.w16b && cw.ks == 3 && (e->conv_impl == 6 || x1) && conv6_supported(Ho, Wo)) {
             // operand-split f16 path, current generation: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
             // then conv6 (pure LDS-DMA + MFMA, two workgroups per CU); GroupNorm statistics of the output come out of its
             // epilogue or of its split-K combine
@@ -299,9 +300,10 @@ struct Fwd {
             DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
             {
                 ProfScope ps(&e->prof, PC_ELEM);
-                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane, e->range_ctr));
+                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, x1 ? nullptr : s16 + plane, e->range_ctr));
             }
             Conv6Args a6;
+            a6.x1 = x1;
             a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16b; a6.w16_scale = cw.w16b_scale;
             a6.bias = cw.bias; a6.out = out; a6.res = res; a6.res_mode = res_mode;
             a6.B = B; a6.Cin = cw.cin; a6.Cout = cw.cout; a6.H = Ho; a6.W = Wo;
@@ -322,7 +324,7 @@ struct Fwd {
             else fused.erase(out);
             return Status{};
         }
-        if (cw.w16 && cw.ks == 3 && conv4_supported(Ho, Wo)) {
+        if (cw.w16 && cw.ks == 3 && !x1 && conv4_supported(Ho, Wo)) {
             // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split), then a
             // convolution that is pure LDS-DMA + MFMA
             int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
@@ -354,7 +356,7 @@ struct Fwd {
             Conv5Args a5;
             a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
             a5.bias = cw.bias; a5.out = out; a5.res = res; a5.B = B; a5.Cout = cw.cout; a5.H = Ho; a5.W = Wo;
-            a5.range_ctr = e->range_ctr;
+            a5.range_ctr = e->range_ctr; a5.x1 = x1;
             fused.erase(out);
             ProfScope ps(&e->prof, PC_CONV1);
             return launch_conv5(s, a5);

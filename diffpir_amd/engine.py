@@ -123,10 +123,11 @@ class Engine:
 
     # ---- UNet
     def set_precision(self, mode):
-        """'f32' (exact fp32 MFMA) or 'f16x3' (operand-split f16 MFMA, fp32-equivalent accuracy); before load_unet."""
-        m = {"f32": 0, "f16x3": 1, 0: 0, 1: 1}[mode]
+        """'f32' (exact fp32 MFMA), 'f16x3' (operand-split f16 MFMA, fp32-equivalent accuracy) or 'f16x1' (f16 operands, fp32
+        accumulation: the reference's use_fp16 recipe -- a REDUCED-precision mode with its own quality contract); before load_unet."""
+        m = {"f32": 0, "f16x3": 1, "f16x1": 2, 0: 0, 1: 1, 2: 2}[mode]
         self._check(self.lib.dpir_set_precision(self.h, m))
-        self.precision = "f16x3" if m else "f32"
+        self.precision = ("f32", "f16x3", "f16x1")[m]
 
     precision = "f32"
 

@@ -23,7 +23,7 @@ import time
 import numpy as np
 import yaml
 
-from . import restore, synth, script_util, utils_model, weights
+from . import restore, synth, script_util, utils_model, weights, degrade as dgr
 from .engine import Engine
 from .utils_inpaint import mask_generator
 
@@ -78,60 +78,42 @@ def sweeps(config):
 
 
 def load_images(config, n_synth):
-    """[N,3,H,W] float32 in [0,1] + names.  testsets/<testset_name>/*.png via PIL when present, else synthetic."""
+    """uint8 [N,H,W,3] (what util.imread_uint returns, main_ddpir.py:84) + names.  testsets/<testset_name>/*.png via PIL when
+    present, else synthetic."""
     d = os.path.join(config.get("cwd", "") or "", "testsets", config.testset_name)
     paths = sorted(glob.glob(os.path.join(d, "*.png")) + glob.glob(os.path.join(d, "*.jpg")))
     if paths and not n_synth:
         try:
             from PIL import Image
-            imgs = [np.asarray(Image.open(p).convert("RGB"), np.float32).transpose(2, 0, 1) / 255.0 for p in paths]
+            imgs = [np.asarray(Image.open(p).convert("RGB"), np.uint8) for p in paths]
             return np.stack(imgs), [os.path.basename(p) for p in paths]
         except Exception as ex:   # pragma: no cover
             log.warning("cannot read %s (%s); using synthetic images", d, ex)
     n = n_synth or 16
     log.info("no dataset on disk: using %d synthetic 256x256 ground-truth images", n)
-    return synth.smooth_images(n, 256, 256, 42), [f"synth_{i:04d}.png" for i in range(n)]
+    f = synth.smooth_images(n, 256, 256, 42)
+    return np.ascontiguousarray((f * 255.0).round().astype(np.uint8).transpose(0, 2, 3, 1)), [f"synth_{i:04d}.png" for i in range(n)]
 
 
-def degrade(config, gt, idx0):
-    """CustomDataset.__getitem__ (main_ddpir.py:46-117) for a batch; returns y, k, mask (numpy, loop layouts)."""
-    from scipy import ndimage
-    B, _, H, W = gt.shape
+def make_operators(config, n, idx0, H, W):
+    """Per-image PSFs / masks of CustomDataset.__getitem__ (main_ddpir.py:52-110): a few hundred scalar operations per image
+    under the numpy RNG, kept on the host so that they stay bit-identical to the reference's.  Returns (k, mask) numpy or None."""
     k = mask = None
     if config.task == "deblur":
         ks = []
-        y = np.empty_like(gt)
-        for b in range(B):
-            np.random.seed(seed=(idx0 + b) * 10)
+        for b in range(n):
+            np.random.seed(seed=(idx0 + b) * 10)                            # main_ddpir.py:59
             if config.blur_mode == "Gaussian":
-                kern = synth.gaussian_psf(config.kernel_size, config.kernel_std * np.abs(np.random.rand() * 2 + 1))
+                ks.append(synth.gaussian_psf(config.kernel_size, config.kernel_std * np.abs(np.random.rand() * 2 + 1)))
             else:
-                kern = synth.motion_psf(config.kernel_size, seed=idx0 + b)
-            ks.append(kern)
-            for c in range(3):
-                y[b, c] = ndimage.convolve(gt[b, c], kern, mode="wrap")
+                ks.append(synth.motion_psf(config.kernel_size, seed=idx0 + b))
         k = np.stack(ks)[:, None].astype(np.float32)
     elif config.task == "sr":
-        y = synth.resize_down(gt, config.sf)
-        k = np.broadcast_to(synth.bicubic_psf_x4(), (B, 1, 25, 25)).copy()
+        k = np.broadcast_to(synth.bicubic_psf_x4(), (n, 1, 25, 25)).copy()
     else:
         gen = mask_generator(config.mask_type, config.mask_len_range, config.mask_prob_range)
-        mask = np.concatenate([gen((1, 3, H, W)) for _ in range(B)], 0)
-        y = gt * mask
-    y = y * 2 - 1
-    y = y + np.random.normal(0, config.noise_level_img * 2, y.shape)
-    y = (y / 2 + 0.5).astype(np.float32)
-    if mask is not None:
-        y = (y * mask).astype(np.float32)
-    return y, k, mask
-
-
-def psnr_per_image(a: np.ndarray, b: np.ndarray, max_pixel=2.0, eps=1e-10) -> np.ndarray:
-    """Per-image terms of utils_image.calculate_psnr_batch (utils/utils_image.py:601-610); their mean is the batch PSNR."""
-    mse = np.mean((a.astype(np.float32) - b.astype(np.float32)) ** 2, axis=(1, 2, 3), dtype=np.float32)
-    with np.errstate(divide="ignore"):
-        v = np.where(mse == 0, np.inf, 20 * np.log10(max_pixel / np.sqrt(mse + np.float32(eps))))
-    return np.where(np.isnan(v), 0.0, v)
+        mask = np.concatenate([gen((1, 3, H, W)) for _ in range(n)], 0)
+    return k, mask
 
 
 def main(argv=None):
@@ -184,39 +166,53 @@ def main(argv=None):
         host_gen = torch.Generator().manual_seed(config.seed)
     results = []
     cache = {}
+    import torch
     for si, (lambda_, zeta) in enumerate(sweeps(config)):
         if args.max_sweeps and si >= args.max_sweeps:
             break
         cfg = loop_config(config, lambda_, zeta)
         if rank == 0:
             log.info("eta:%s, zeta:%s, lambda:%s, guidance_scale:%s", config.eta, zeta, lambda_, config.guidance_scale)
-        psnrs, t0, n = [], time.time(), 0
+        psnrs, psnrs_y, t0, n = [], [], time.time(), 0
         for i0 in range(0, len(imgs), config.batch_size):
-            gt = imgs[i0:i0 + config.batch_size]
-            y, k, mask = degrade(config, gt, i0)                     # every rank synthesises the same global batch (seeded numpy)
-            drawn = None
-            if noise == "host":
-                import torch
-                _, steps, _ = restore._steps(cfg)
-                nf = lambda shape: torch.randn(tuple(shape), generator=host_gen).numpy()
-                drawn = restore.draw_host_noise(nf, steps, (len(gt), 3, gt.shape[2], gt.shape[3]), cfg.eta != 0,
-                                                repaint=cfg.generate_mode == "repaint")
-            u8, out_f32 = ddist.restore_sharded(eng, cfg, y, k=k, mask=mask, rank=rank, world=world, image_offset=i0, seed=config.seed,
-                                                use_graph=use_graph, noise_source=noise, host_noise=drawn, cache=cache,
+            gt = imgs[i0:i0 + config.batch_size]                           # uint8 [n,H,W,3]
+            n_b, H, W = gt.shape[0], gt.shape[1], gt.shape[2]
+            k_all, mask_all = make_operators(config, n_b, i0, H, W)      # every rank draws the same operators (seeded numpy)
+            lo, hi = ddist.shard_range(n_b, rank, world)                 # this rank's images of the batch
+            per_img = np.zeros(0)
+            u8_local = torch.empty((hi - lo, H, W, 3), dtype=torch.uint8, device=f"cuda:{eng.device}")
+            if hi > lo:
+                sl = slice(lo, hi)
+                # degradation on the device (dpir_degrade): blur / down-sampling / masking + AWGN, device Philox noise keyed by the
+                # global image index
+                y, ops = dgr.degrade(eng, config.task, gt[sl], k=None if k_all is None else k_all[sl], mask=None if mask_all is None else mask_all[sl],
+                                     noise_level_img=config.noise_level_img, sf=config.sf, sr_mode=config.sr_mode, seed=config.seed + 1,
+                                     image_offset=i0 + lo)
+                drawn = None
+                if noise == "host":
+                    _, steps, _ = restore._steps(cfg)
+                    nf = lambda shape: torch.randn(tuple(shape), generator=host_gen).numpy()
+                    full = restore.draw_host_noise(nf, steps, (n_b, 3, H, W), cfg.eta != 0, repaint=cfg.generate_mode == "repaint")
+                    drawn = [None if a is None else (np.ascontiguousarray(a[sl]) if a.ndim == 4 else np.ascontiguousarray(a[:, sl])) for a in full]
+                out_f32 = restore.restore_batch(eng, cfg, y, k=ops.get("k"), mask=ops.get("mask"), noise_source=noise, predrawn=drawn,
+                                                seed=config.seed, image_offset=i0 + lo, use_graph=use_graph, out_u8=u8_local, _cache=cache,
                                                 skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False)))
-            lo, hi = ddist.shard_range(len(gt), rank, world)
-            import torch
-            local = psnr_per_image(out_f32.numpy() * 2 - 1, gt[lo:hi] * 2 - 1) if hi > lo else np.zeros(0)
-            per_img = ddist.all_gather_results(torch.from_numpy(np.asarray(local, np.float64)), len(gt), rank, world).numpy()
-            p = float(np.mean(per_img))
-            psnrs.append(p * len(gt))
-            n += len(gt)
+                psnr_i, psnr_y_i = dgr.metrics(eng, out_f32, ops["gt"])            # dpir_metrics: per-image PSNR / PSNR-Y
+                per_img = np.stack([psnr_i, psnr_y_i], 1).astype(np.float64)
+            u8 = ddist.all_gather_results(u8_local, n_b, rank, world)           # the one collective of the path
+            allm = ddist.all_gather_results(torch.from_numpy(per_img.reshape(-1, 2)), n_b, rank, world).numpy()
+            p, p_y = float(np.mean(allm[:, 0])), float(np.mean(allm[:, 1]))
+            psnrs.append(p * n_b)
+            psnrs_y.append(p_y * n_b)
+            n += n_b
             if rank == 0:
                 log.info("batch%4d--> PSNR: %.4fdB", i0 // config.batch_size + 1, p)
         dt = time.time() - t0
         if rank == 0:
             log.info("-----------> Average PSNR(RGB) of (%s) scale factor: (%d), sigma: (%.3f): %.4f dB  [%.2f images/s on %d GPU(s)]",
                      config.testset_name, config.sf, config.noise_level_model, sum(psnrs) / n, n / dt, world)
+            log.info("-----------> Average PSNR(Y) of (%s) scale factor: (%d), sigma: (%.3f): %.4f dB",
+                     config.testset_name, config.sf, config.noise_level_model, sum(psnrs_y) / n)
         results.append(sum(psnrs) / n)
     ddist.shutdown()
     eng.close()

@@ -97,7 +97,10 @@ int dpir_load_unet(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor
 /* Arithmetic of the convolution / attention GEMMs, to be chosen BEFORE dpir_load_unet (weights are packed for it):
  *   0  exact fp32 MFMA (v_mfma_f32_32x32x2_f32), the default;
  *   1  operand-split f16 MFMA: x = hi + lo in f16, 3 x v_mfma_f32_32x32x16_f16 per product, fp32 accumulation --
- *      22-bit products, measured error <= the fp32 MFMA chain's, 5.3x its rate. */
+ *      22-bit products, measured error <= the fp32 MFMA chain's, 5.3x its rate;
+ *   2  f16x1: f16 operands (weights and activations rounded once to f16), ONE MFMA per product, fp32 accumulation, fp32
+ *      GroupNorm / softmax / residual stream -- the reference's own reduced-precision recipe (guided_diffusion/fp16_util.py:15-32,
+ *      unet.py:618-632 `use_fp16`).  NOT within the 1e-3 dB parity contract: its measured quality delta is reported by bench.py. */
 int dpir_set_precision(dpir_engine* e, int mode);
 
 /* Replaces UNetModel.forward (guided_diffusion/unet.py:634-663): x_dev [B,3,H,W], t_host [B] int64
@@ -210,6 +213,28 @@ typedef struct dpir_loop_desc {
  * out_f32_dev [B,3,H,W] in [0,1] un-clamped (x_0 of main_ddpir.py:470), out_u8_dev [B,H,W,3]. */
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
                   float* out_f32_dev, uint8_t* out_u8_dev);
+
+/* ---- degradation synthesis and metrics: the steps either side of the loop ------------------ */
+/* Replaces CustomDataset.__getitem__'s arithmetic (main_ddpir.py:84-114) on the device.  gt_u8_dev: ground truth, uint8
+ * [B,H,W,3] (what util.imread_uint returns).  deblur: scipy.ndimage.convolve(img_H, k, mode='wrap') on the uint8 image (float64
+ * accumulation, result cast back to uint8) / 255; sr (both sr_modes): utils_image.imresize_np(img_H / 255, 1 / sf) (== the Resizer
+ * weights); inpaint: img_H * mask / 255.  Then img_L*2-1 + N(0, (2*noise_level_img)^2), /2 + 0.5 in float64 (:112-114) and, for
+ * inpainting, * mask (:311-313).  noise_dev: [B,3,h,w] standard-normal floats (host-fed) or NULL -> device Philox keyed by
+ * (seed, image_offset + b).  y_out_dev: [B,3,H/sf,W/sf] float32 in [0,1]. */
+typedef struct dpir_degrade_desc {
+    int32_t task;                 /* dpir_task */
+    int32_t B, H, W, sf;
+    int32_t kh, kw;               /* deblur PSF size */
+    float noise_level_img;        /* already / 255 (main_ddpir.py:138) */
+    uint64_t seed;
+    int64_t image_offset;
+} dpir_degrade_desc;
+int dpir_degrade(dpir_engine* e, const dpir_degrade_desc* d, const uint8_t* gt_u8_dev, const float* k_dev, const uint8_t* mask_dev,
+                 const float* noise_dev, float* y_out_dev);
+/* Replaces main_ddpir.py:482-517: per image, PSNR of x_0*2-1 against img_H/255*2-1 (utils_image.calculate_psnr_batch terms,
+ * max_pixel 2, eps 1e-10) and the same on the Y channel of rgb2ycbcr_batch(only_y) (utils_image.py:470-490; its two zero
+ * channels are part of the mean, as in the reference).  x0_dev [B,3,H,W] in [0,1]; outputs: HOST arrays of B floats (syncs). */
+int dpir_metrics(dpir_engine* e, const float* x0_dev, const uint8_t* gt_u8_dev, int B, int H, int W, float* psnr_host, float* psnr_y_host);
 
 /* ---- instrumentation --------------------------------------------------------------------- */
 /* Kernel-time accounting with HIP events on the engine stream.  class ids: 0 conv3x3, 1 conv1x1,

@@ -219,3 +219,21 @@ def test_schedule_corner_cases_match_live_reference(golden):
     assert int(g["duplast_n_last"]) == 2
     out = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(int(g["duplast_seed"])))
     np.testing.assert_allclose(out.numpy(), g["duplast_out"], rtol=0, atol=2e-5)
+
+
+def test_degradation_and_metrics_oracle_matches_live_reference(golden):
+    """oracle/degrade_oracle.py against tests/golden/degrade.npz (scipy.ndimage.convolve on the uint8 image, the reference's
+    utils_image.imresize_np / calculate_psnr_batch / rgb2ycbcr_batch; oracle/gen_golden_degrade.py)."""
+    from oracle import degrade_oracle as dg
+    g = golden("degrade")
+    y = dg.degrade("deblur", g["gt"], k=g["k"], noise_level_img=12.75 / 255, noise=g["noise"])
+    np.testing.assert_array_equal(y, g["deblur_y"])
+    np.testing.assert_array_equal(dg.degrade("deblur", g["gt"], k=g["k"]), g["deblur_y_sigma0"])
+    q = np.round(g["deblur_y_clean"] * 255)
+    assert np.abs(q - g["deblur_y_clean"] * 255).max() < 1e-4          # the blurred image is uint8-quantised (convolve on uint8)
+    np.testing.assert_allclose(dg.degrade("sr", g["gt"], sf=4), g["sr4_y_clean"], atol=3e-7)
+    np.testing.assert_array_equal(dg.degrade("inpaint", g["gt"], mask=g["mask"]), g["inpaint_y"])
+    p, py = dg.metrics(g["x0"], g["gt"])
+    np.testing.assert_array_equal(p, g["psnr"])
+    np.testing.assert_array_equal(py, g["psnr_y"])
+    assert abs(float(np.mean(p)) - float(g["psnr_batch"])) < 1e-5
