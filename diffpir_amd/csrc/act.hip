@@ -1,9 +1,9 @@
-// act_split: the activation pre-pass of the operand-split f16 convolution path (conv4.hip).
+// act_split: the activation pre-pass of the operand-split f16 convolution path (conv6.hip).
 //
 // One HBM-bound elementwise kernel applies everything the reference runs between two convolutions --
 // GroupNorm affine (nn.py:17-19), FiLM scale/shift (unet.py:250-251), SiLU (unet.py:184,208), 2x2 average pooling or
 // nearest x2 up-sampling (unet.py:107,136) and the channel concat (unet.py:660) -- ONCE per element, splits the
-// result into f16 hi/lo halves (x = hi + lo) and stores it in the blocked layout [n][C/8][H][W][8] that conv4's
+// result into f16 hi/lo halves (x = hi + lo) and stores it in the blocked layout [n][C/8][H][W][8] that conv6's
 // LDS-DMA copies straight into MFMA B-operand order.  Bytes per element: 4 read + 4 written.
 #include "common.h"
 

@@ -109,30 +109,18 @@ struct ConvArgs {
     int dbg = 0;                  // ablation bits (debug bench only)
 };
 Status launch_conv(hipStream_t s, const ConvArgs& a);
-float pack_weights_f16x3(const float* w_oihw, int cout, int cin, int ks, std::vector<uint16_t>& out);
 inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
 // norm.hip
 struct CatSrc { const float* a; int ca; const float* b; int cb; };
 
-// act.hip + conv4.hip: operand-split f16 path with a separate activation pre-pass
+// act.hip: the activation pre-pass of the operand-split f16 path (GroupNorm apply / FiLM / SiLU / resampling / concat / split)
 // hi / lo: blocked [B][C8][H][W][8] f16 planes, C8 = 2*ceil(C/16); mode: 0 plain, 1 nearest-up source, 2 avg-pool source
 // range_ctr: device counter of operand values outside the f16 range (see act.hip range_report), or null
 // lo == nullptr: single-product mode, only the hi plane is produced
 Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo,
                         unsigned long long* range_ctr = nullptr);
-struct Conv4Args {
-    const void* xhi = nullptr; const void* xlo = nullptr;   // split activations (Cin channels, output resolution)
-    const void* w16 = nullptr; float w16_scale = 1.f;
-    const float* bias = nullptr; float* out = nullptr; const float* res = nullptr; int res_mode = 0;
-    int B = 0, Cin = 0, Cout = 0, H = 0, W = 0;
-    float* partial = nullptr; size_t partial_capacity = 0; int dbg = 0;
-    float2* stat = nullptr;   // optional [B][Cout][conv4_stat_slots(H, W)] GroupNorm partial sums of the output
-};
-bool conv4_supported(int H, int W);
-int conv4_stat_slots(int H, int W);
-Status launch_conv4(hipStream_t s, const Conv4Args& a, bool* stat_written = nullptr);
-// conv6.hip: 3x3, f16x3, two workgroups per CU (private weight rings); same activation planes as conv4
+// conv6.hip: 3x3, f16x3 (or f16x1), two workgroups per CU (private weight rings)
 struct Conv6Args {
     const void* xhi = nullptr; const void* xlo = nullptr;
     const void* w16 = nullptr; float w16_scale = 1.f;       // pack_weights_conv6 layout
@@ -161,7 +149,7 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a);
 float pack_weights_f16x3_1x1(const float* w_oi, int cout, int cin, std::vector<uint16_t>& out);
 // part[n*C+c] = fp64 {sum, sum of squares} of one channel plane of the (virtual-concat) input
 Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part);
-// statistics of one tensor of a virtual concat: conv4 epilogue slots [B][c][nslots] (float2) or, when slots == null,
+// statistics of one tensor of a virtual concat: conv6 epilogue slots [B][c][nslots] (float2) or, when slots == null,
 // gn_stats partials [B][c] (double2)
 struct GnStatSrc { const float2* slots = nullptr; int nslots = 0; const double2* part = nullptr; int c = 0; };
 // prm[n*C+c] = {mean, rstd*gamma*(1+scale), beta*(1+scale)+shift, silu?1:0}; film = [B, film_stride] rows with

@@ -17,6 +17,13 @@
 // [KC][TI][TH+2][TW+2] are staged in LDS once per chunk and reused by all 9 taps.
 #include "common.h"
 
+// Ablation switches exist only in -DDPIR_ABLATE builds; the product kernels contain none of them.
+#ifdef DPIR_ABLATE
+#define ABL(bit) ((p.dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 namespace dpir {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -151,7 +158,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
     float4 wreg[NWV];
     float vals[KC][NP];
     auto load_chunk = [&](int c0) {
-        if (p.dbg & 4) {
+        if (ABL(4)) {
 #pragma unroll
             for (int u = 0; u < NWV; ++u) wreg[u] = make_float4(0.5f, 0.25f, 0.125f, 1.f);
 #pragma unroll
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
         for (int u = 0; u < NWV; ++u) {
             int v = tid + u * 256;
-            if (v < NV && !(p.dbg & 8)) {
+            if (v < NV && !ABL(8)) {
                 int co4 = v % (BCO / 4);
                 int t2 = v / (BCO / 4);
                 int tap = t2 % TAPS;
@@ -223,12 +230,12 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
                 for (int q = 0; q < NP; ++q) {
                     if (pos_lds[q] < 0) continue;
                     float v = vals[k][q];
-                    if (p.prm && !(p.dbg & 2)) {
+                    if (p.prm && !ABL(2)) {
                         float4 m = lds_prm[(pbuf * KC + k) * 8 + pos_ti[q]];
                         v = (v - m.x) * m.y + m.z;
                         if (m.w != 0.f) v = silu_f(v);
                     }
-                    if (!(p.dbg & 8)) lds_x[k * p.chs + pos_lds[q]] = (cok && pos_ok[q]) ? v : 0.f;
+                    if (!ABL(8)) lds_x[k * p.chs + pos_lds[q]] = (cok && pos_ok[q]) ? v : 0.f;
                 }
             }
         } else {
@@ -263,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
         // ---- MFMA over taps x channel pairs.  Operands are read from LDS one STAGE (2 k-steps = 8 MFMAs per
         // wave, ~500 cycles) ahead into a second register set, so ds_read latency never sits in front of an MFMA
         // (the compiler's own schedule re-used one A register pair and waited lgkmcnt(0) every 4 MFMAs).
-        if (!(p.dbg & 1)) {
+        if (!ABL(1)) {
             constexpr int KSTEPS = KC / 2;
             constexpr int NSTEP = TAPS * KSTEPS;
             constexpr int SG = 2;                       // k-steps per stage (8 MFMAs per wave, ~500 cycles of cover)
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(256, 2) void conv_mfma_kernel(ConvK p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 int co = co0 + (wave_co * WCO + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (p.dbg & 16) {
+                if (ABL(16)) {
                     if (acc[i][j][r] == 1.2345e33f) p.out[0] = 1.f;   // keep the accumulators live
                 } else if (pok && co < p.Cout && p.ksplit > 1) {
                     p.partial[(size_t)split * ((size_t)p.B * p.Cout * HW) + ((size_t)n * p.Cout + co) * HW + y * p.W + x] = acc[i][j][r];
@@ -433,7 +440,7 @@ Status launch_conv(hipStream_t s, const ConvArgs& a) {
     if (eh != a.src.Hs || ew != a.src.Ws) return invalid("conv: source resolution does not match mode");
     if (a.src.mode == 1 && ((a.H | a.W) & 1)) return invalid("conv: up mode needs even output size");
     // generation-2 kernel (conv2.hip) for plain / up-sampled sources; the pooled-source variant stays on v1
-    if (a.src.mode != 2 && !(a.dbg & 32) && a.CoutP % 64 == 0) return launch_conv2(s, a);
+    if (a.src.mode != 2 && a.CoutP % 64 == 0) return launch_conv2(s, a);
     // pixel tile: TW x TH x TI = 128
     int tw = a.W >= 32 ? 32 : (a.W >= 16 ? 16 : (a.W >= 8 ? 8 : 4));
     int th = 128 / tw;

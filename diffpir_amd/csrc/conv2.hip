@@ -16,6 +16,13 @@
 // of 64 (zero columns), so the weight DMA needs no bounds check.
 #include "common.h"
 
+// Ablation switches exist only in -DDPIR_ABLATE builds; the product kernels contain none of them.
+#ifdef DPIR_ABLATE
+#define ABL(bit) ((p.dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
 namespace dpir {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
@@ -135,7 +142,7 @@ __global__ __launch_bounds__(256, 2) void conv2_mfma_kernel(Conv2K p) {
 
     // all DMAs of one chunk (starting at input channel c0) into LDS buffer `buf`
     auto issue_dma = [&](int c0, int buf) {
-        if (p.dbg & 4) return;
+        if (ABL(4)) return;
         // weights: piece = 4 rows x 256 B, pieces round-robin over the 4 waves
 #pragma unroll
         for (int u = 0; u < (NDMA + 3) / 4; ++u) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void conv2_mfma_kernel(Conv2K p) {
     };
     // in-place prologue transform of the elements this thread's own DMAs delivered
     auto transform_acts = [&](int buf, int cbase) {
-        if (p.dbg & 8) return;
+        if (ABL(8)) return;
         float* dst = lds_x + buf * KC * XS;
         const float4* prm = lds_prm + (buf * 4 + wave) * PRM;
 #pragma unroll
@@ -179,7 +186,7 @@ __global__ __launch_bounds__(256, 2) void conv2_mfma_kernel(Conv2K p) {
             for (int q = 0; q < NP; ++q) {
                 const int idx = k * XS + tid + q * 256;
                 float v = dst[idx];
-                if (p.prm && !(p.dbg & 2)) {
+                if (p.prm && !ABL(2)) {
                     float4 m = prm[k * 8 + pos_ti[q]];
                     v = (v - m.x) * m.y + m.z;
                     if (m.w != 0.f) v = silu2_f(v);
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv2_mfma_kernel(Conv2K p) {
         const bool more = c0 + KC < c_end;
         if (more) issue_dma(c0 + KC, cur ^ 1);
 
-        if (!(p.dbg & 1)) {
+        if (!ABL(1)) {
             constexpr int KSTEPS = KC / 2;
             constexpr int NSTEP = TAPS * KSTEPS;
             constexpr int SG = 2;
@@ -254,7 +261,7 @@ __global__ __launch_bounds__(256, 2) void conv2_mfma_kernel(Conv2K p) {
         int ti = pp >> (p.ltw + p.lth);
         int n = n0 + ti, y = ty0 + py, x = tx0 + px;
         bool pok = ti < TI && n < p.B && y < p.H && x < p.W;
-        if (p.dbg & 16) {
+        if (ABL(16)) {
 #pragma unroll
             for (int i = 0; i < WCO; ++i)
 #pragma unroll

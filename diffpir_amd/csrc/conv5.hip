@@ -1,5 +1,5 @@
 // conv5: 1x1 convolution (pointwise GEMM  out[co, px] = W[co, ci] * X[ci, px]) on the f16 matrix pipe with operand
-// splitting (arithmetic and accuracy: see conv3.hip).  Unlike the 3x3 case there is no 9-tap reuse to amortise a
+// splitting (arithmetic and accuracy: see conv6.hip).  Unlike the 3x3 case there is no 9-tap reuse to amortise a
 // separate split pre-pass over, so the fp32 NCHW activations are DMA'd straight into LDS ([16 ch][256 px] per K chunk,
 // one 1 KiB piece per channel row; the virtual concat is resolved per piece) and each lane splits its own B fragment
 // (8 channels of one pixel) into f16 hi/lo on the VALU, which runs beside the f16 MFMA pipe.
@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int half = lane >> 5;
-    const int bid = blockIdx.x;             // plain order: measured faster than the XCD renumbering conv4.hip uses
+    const int bid = blockIdx.x;             // plain order: measured faster than the XCD renumbering conv6.hip uses
     const int co_blk = bid % p.n_co_blocks;
     const long long px0 = (long long)(bid / p.n_co_blocks) * 256;
     const int C = p.ca + p.cb;

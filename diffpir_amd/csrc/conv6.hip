@@ -1,11 +1,21 @@
-// conv6: 3x3 implicit-GEMM convolution on the f16 matrix pipe with operand splitting (x = hi + lo, three
-// v_mfma_f32_32x32x16_f16 per fp32-equivalent product, see conv4.hip) -- the TWO-WORKGROUPS-PER-CU generation.
+// conv6: 3x3 implicit-GEMM convolution on the f16 matrix pipe with OPERAND SPLITTING: every fp32 operand is split into two f16
+// halves (x = hi + lo, hi = f16(x), lo = f16(x - hi)) and each product is evaluated as
+//     lo_w*hi_x + hi_w*lo_x + hi_w*hi_x                (3 x v_mfma_f32_32x32x16_f16, fp32 accumulate, small terms first)
+// i.e. a 22-bit-mantissa product; the dropped lo*lo term is 2^-22 relative.  Measured on this chip
+// (tools/micro/mfma_f16x3_probe.hip): max error of a K=16 dot product 2.7e-7 vs 4.5e-7 for the exact-fp32 MFMA chain, f16
+// subnormal inputs are NOT flushed, operand mapping A[i][8g+j] / B[8g+j][i'] for lane (i = l%32, g = l/32), element j.  Weights
+// are pre-scaled by a per-layer power of two (exactly undone in the epilogue) so that their low halves stay normal.
+// Why: fp32 MFMA runs at the vector rate (157 TF/s), f16 MFMA has its own pipe at 2.5 PF/s: 3 MFMAs per product = 833 TF/s
+// fp32-equivalent.  The activation operand arrives already normalised, activated, resampled, concatenated and split
+// (act.hip), so the kernel is pure LDS-DMA + MFMA.
 //
-// Why a new structure.  conv4 keeps one 156 KiB workgroup per CU: its prologue (first operand DMA, ~2 us), its epilogue
+// Structure: TWO WORKGROUPS PER CU.  The previous generation (round 1's conv4: 64 co x 512 px, 8 waves, weights of a K chunk
+// staged once for all waves) kept one 156 KiB workgroup per CU: its prologue (first operand DMA, ~2 us), its epilogue
 // (64 co x 512 px fp32 = 128 KiB of stores + as much residual, bound by the per-CU store issue rate: 6-9 us) and its
 // barrier bubbles are all serialised with the MFMA stream -- at Cin = 128 the matrix pipe is busy 27.6 us of a 55 us
 // workgroup lifetime.  Here a workgroup needs 76 KiB of LDS and <= 256 VGPRs, so the hardware keeps TWO resident per CU
 // (two waves per SIMD, one from each) and one workgroup's prologue / epilogue / barrier waits run under the other's MFMAs.
+// Measured in the network (FFHQ, B = 16): 3x3 class 17.1 -> 16.3 ms per forward, isolated layers -8 ... -17 %.
 //
 // What made the LDS fit.  The 36 KiB weight stage of conv4 (64 co x 16 ci x 9 taps x hi/lo, shared by 8 waves, double
 // buffered = 72 KiB) is gone: the workgroup tile is 128 output channels x 256 pixels and each of the 4 waves owns
@@ -133,7 +143,8 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
-    // XCD-aware order (conv4.hip): one XCD owns a contiguous range of tiles
+    // XCD-aware order: workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2); renumber them so that one XCD
+    // owns a contiguous range of tiles (the co-blocks of a pixel tile and neighbouring tiles share an L2)
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);
     const int split = bid % p.ksplit;

@@ -27,8 +27,7 @@ struct Workspace {
 };
 
 struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3;
-               void* w16 = nullptr; float w16_scale = 1.f;      // operand-split f16 copy (precision mode 1): conv4 / conv5 layout
-               void* w16b = nullptr; float w16b_scale = 1.f; }; // 3x3 only: conv6 layout (per-wave records)
+               void* w16 = nullptr; float w16_scale = 1.f; };   // operand-split f16 copy (precision modes 1, 2): conv6 layout for 3x3, conv5 layout for 1x1
 struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 struct ResW {
     std::string name;
@@ -86,7 +85,6 @@ struct dpir_engine {
     std::vector<void*> user_allocs;
     bool collect_taps = true;
     int precision = 0;           // 0: exact fp32 MFMA kernels; 1: operand-split f16x3 MFMA (fp32-equivalent accuracy)
-    int conv_impl = 6;           // f16x3 3x3 kernel generation: 6 = conv6 (two workgroups per CU), 4 = conv4 (DIFFPIR_CONV=4, A/B runs)
     // Captured restoration steps.  A graph depends only on what is baked into its kernel arguments: the shape / task /
     // mode fields below and the workspace generation; per-batch pointers, seed and image offset live in a device block
     // (dpir::LoopDev), so every batch of a test set replays the same graph.  Entries are compared field by field on a

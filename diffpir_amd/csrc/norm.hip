@@ -67,7 +67,7 @@ Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part) 
     return Status{};
 }
 
-// One workgroup per (image, group): folds the group's per-channel statistics in fp64 - conv4 epilogue slots
+// One workgroup per (image, group): folds the group's per-channel statistics in fp64 - conv6 epilogue slots
 // (float2 per 64-pixel wave) or gn_stats partials (double2 per plane), per source tensor of the virtual concat - in a
 // fixed order (thread-strided, then the usual wave/LDS tree), and writes the per-channel affine parameters.
 __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,

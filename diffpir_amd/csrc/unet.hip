@@ -82,20 +82,12 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     DPIR_TRY(upload(e, b, cout, &out->bias));
     if (e->precision >= 1 && (ks == 3 || ks == 1)) {
         std::vector<uint16_t> w16;
-        out->w16_scale = ks == 3 ? pack_weights_f16x3(w, cout, cin, ks, w16) : pack_weights_f16x3_1x1(w, cout, cin, w16);
+        out->w16_scale = ks == 3 ? pack_weights_conv6(w, cout, cin, w16) : pack_weights_f16x3_1x1(w, cout, cin, w16);
         void* p = nullptr;
         if (hipMalloc(&p, w16.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for split weights failed"};
         e->net.allocs.push_back(p);
         DPIR_HIP(hipMemcpy(p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
         out->w16 = p;
-        if (ks == 3) {
-            out->w16b_scale = pack_weights_conv6(w, cout, cin, w16);
-            void* q = nullptr;
-            if (hipMalloc(&q, w16.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for split weights failed"};
-            e->net.allocs.push_back(q);
-            DPIR_HIP(hipMemcpy(q, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
-            out->w16b = q;
-        }
     }
     return Status{};
 }
@@ -287,8 +279,8 @@ struct Fwd {
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
         const bool x1 = e->precision == 2;        // f16x1: single-product mode, hi halves only
-        if (cw.w16b && cw.ks == 3 && (e->conv_impl == 6 || x1) && conv6_supported(Ho, Wo)) {
-            // operand-split f16 path, current generation: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
+        if (cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo)) {
+            // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
             // then conv6 (pure LDS-DMA + MFMA, two workgroups per CU); GroupNorm statistics of the output come out of its
             // epilogue or of its split-K combine
             int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
@@ -304,7 +296,7 @@ struct Fwd {
             }
             Conv6Args a6;
             a6.x1 = x1;
-            a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16b; a6.w16_scale = cw.w16b_scale;
+            a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16; a6.w16_scale = cw.w16_scale;
             a6.bias = cw.bias; a6.out = out; a6.res = res; a6.res_mode = res_mode;
             a6.B = B; a6.Cin = cw.cin; a6.Cout = cw.cout; a6.H = Ho; a6.W = Wo;
             a6.partial = partial; a6.partial_capacity = partial_cap;
@@ -322,34 +314,6 @@ struct Fwd {
             if (kind == 1) fused[out] = FusedStat{st, slots, nullptr};
             else if (kind == 2) fused[out] = FusedStat{nullptr, 0, sp};
             else fused.erase(out);
-            return Status{};
-        }
-        if (cw.w16 && cw.ks == 3 && !x1 && conv4_supported(Ho, Wo)) {
-            // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split), then a
-            // convolution that is pure LDS-DMA + MFMA
-            int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
-            if (eh != in.H || ew != in.W) return invalid("conv: source resolution does not match mode");
-            const int C = in.C(), C8 = 2 * ((C + 15) / 16);
-            const size_t plane = (size_t)B * C8 * Ho * Wo * 16;
-            char* s16 = nullptr;
-            DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
-            {
-                ProfScope ps(&e->prof, PC_ELEM);
-                DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, s16 + plane, e->range_ctr));
-            }
-            Conv4Args a4;
-            a4.xhi = s16; a4.xlo = s16 + plane; a4.w16 = cw.w16; a4.w16_scale = cw.w16_scale;
-            a4.bias = cw.bias; a4.out = out; a4.res = res; a4.res_mode = res_mode;
-            a4.B = B; a4.Cin = cw.cin; a4.Cout = cw.cout; a4.H = Ho; a4.W = Wo;
-            a4.partial = partial; a4.partial_capacity = partial_cap;
-            const int slots = conv4_stat_slots(Ho, Wo);
-            float2* st = nullptr;
-            if (slots > 0 && cw.cout % 32 == 0) DPIR_TRY(ws.getT("st#" + std::to_string(reinterpret_cast<uintptr_t>(out)), (size_t)B * cw.cout * slots, &st));
-            a4.stat = st;
-            bool wrote = false;
-            ProfScope ps(&e->prof, PC_CONV3);
-            DPIR_TRY(launch_conv4(s, a4, &wrote));
-            if (wrote) fused[out] = FusedStat{st, slots, nullptr}; else fused.erase(out);
             return Status{};
         }
         if (cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo)) {
