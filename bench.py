@@ -207,6 +207,8 @@ def main():
         return e
 
     eng = load(args.model, args.precision)
+    if os.environ.get("DIFFPIR_COLLECTIVE") == "rccl":      # opt-in: the result all-gather through the C ABI (ncclAllGather via dlopen)
+        ddist.init_rccl(eng, rank, world)
     B, H = args.batch, args.size
     cfg, case = make_problem(restore, synth, args.task, B, H, args.nfe, 100 + rank)
     y = eng.to_device(case["y"])
@@ -222,7 +224,7 @@ def main():
         restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source="device", seed=1234, image_offset=rank * B,
                               use_graph=not args.no_graph, out_f32=out_f32, out_u8=out_u8, _cache=keep)
         eng.sync()
-        ddist.all_gather_results(out_u8, B * world, rank, world)
+        ddist.all_gather_results(out_u8, B * world, rank, world, engine=eng)
 
     def fence():
         eng.sync()

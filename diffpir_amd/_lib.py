@@ -83,6 +83,10 @@ SIGNATURES = {
     "dpir_repaint_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dpir_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "dpir_allgather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dpir_comm_destroy": (C.c_int, [C.c_void_p]),
     "dpir_degrade": (C.c_int, [C.c_void_p, C.POINTER(DegradeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dpir_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "dpir_run_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.c_int, C.c_void_p, C.c_void_p]),

@@ -132,6 +132,7 @@ void dpir_destroy(dpir_engine* e) {
     for (void* p : e->user_allocs) (void)hipFree(p);
     e->invalidate_graphs();
     prox_release(&e->loop_prox);
+    (void)dpir_comm_destroy(e);
     if (e->range_ctr) (void)hipFree(e->range_ctr);
     (void)hipStreamDestroy(e->stream);
     delete e;

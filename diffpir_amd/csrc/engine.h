@@ -105,6 +105,7 @@ struct dpir_engine {
         graphs.clear();
     }
     unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
+    void* comm = nullptr; int comm_world = 1, comm_rank = 0;     // RCCL communicator (comm.cpp), or null
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);
     dpir::Status fft2_table(int N, const float2** out);

@@ -59,11 +59,68 @@ def shutdown():
         dist.destroy_process_group()
 
 
-def all_gather_results(local, n_images: int, rank: int, world: int):
+def init_rccl(engine, rank: int, world: int, port: int = None):
+    """Bind the result collective straight to RCCL through the C ABI (dpir_comm_init / dpir_allgather_results): rank 0 creates
+    the 128-byte ncclUniqueId and ships it to the other ranks over a TCP socket on MASTER_ADDR (stdlib; rendezvous plumbing
+    only), then every rank joins the communicator on its engine's device.  Selected with DIFFPIR_COLLECTIVE=rccl."""
+    import ctypes as C
+    import socket
+    import time
+    buf = C.create_string_buffer(128)
+    addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
+    port = port or int(os.environ.get("MASTER_PORT", "29533")) + 17
+    if rank == 0:
+        engine._check(engine.lib.dpir_comm_unique_id(buf))
+        if world > 1:
+            srv = socket.socket()
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port))
+            srv.listen(world)
+            for _ in range(world - 1):
+                c, _a = srv.accept()
+                c.sendall(buf.raw)
+                c.close()
+            srv.close()
+    else:
+        for attempt in range(600):
+            try:
+                c = socket.create_connection((addr, port), timeout=5)
+                break
+            except OSError:
+                time.sleep(0.1)
+        else:
+            raise RuntimeError("RCCL rendezvous: rank 0 is not listening")
+        data = b""
+        while len(data) < 128:
+            chunk = c.recv(128 - len(data))
+            if not chunk:
+                raise RuntimeError("RCCL rendezvous: short read of the unique id")
+            data += chunk
+        c.close()
+        buf.raw = data
+    engine._check(engine.lib.dpir_comm_init(engine.h, world, rank, buf))
+    engine.rccl = True
+
+
+def all_gather_results(local, n_images: int, rank: int, world: int, engine=None):
     """local: torch tensor [n_local, ...] (uint8 NHWC results).  Returns [n_images, ...] on every rank.
-    Shards may differ by one image, so each is padded to the largest shard for the collective."""
+    Shards may differ by one image, so each is padded to the largest shard for the collective.
+    engine with an RCCL communicator (init_rccl): ncclAllGather through the C ABI on the engine stream; otherwise
+    torch.distributed (backend nccl == RCCL, or gloo in the single-GPU / CPU tests)."""
     import torch
     import torch.distributed as dist
+    if engine is not None and getattr(engine, "rccl", False):
+        sizes = [shard_range(n_images, r, world) for r in range(world)]
+        mx = max(hi - lo for lo, hi in sizes)
+        pad = local
+        if local.shape[0] < mx:
+            pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], 0)
+        pad = pad.contiguous()
+        recv = torch.empty((world,) + tuple(pad.shape), dtype=pad.dtype, device=pad.device)
+        torch.cuda.current_stream(pad.device).synchronize()          # `pad` may have been produced on torch's stream
+        engine._check(engine.lib.dpir_allgather_results(engine.h, pad.data_ptr(), recv.data_ptr(), pad.numel() * pad.element_size()))
+        engine.sync()
+        return torch.cat([recv[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
     if world == 1:
         return local
     sizes = [shard_range(n_images, r, world) for r in range(world)]
@@ -111,4 +168,4 @@ def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int
         engine.sync()
     else:
         out_f32 = None
-    return all_gather_results(out_u8, n, rank, world), out_f32
+    return all_gather_results(out_u8, n, rank, world, engine=engine), out_f32

@@ -140,6 +140,8 @@ def main(argv=None):
     np.random.seed(config.seed)
     eng = Engine(args.device if args.device is not None else local_rank)
     eng.set_precision(str(config.get("engine_precision", "f16x3")))      # before load_state_dict: selects the weight packing
+    if os.environ.get("DIFFPIR_COLLECTIVE") == "rccl":
+        ddist.init_rccl(eng, rank, world)
 
     model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
                         num_channels=128, num_res_blocks=1, attention_resolutions="16") \
@@ -199,7 +201,7 @@ def main(argv=None):
                                                 skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False)))
                 psnr_i, psnr_y_i = dgr.metrics(eng, out_f32, ops["gt"])            # dpir_metrics: per-image PSNR / PSNR-Y
                 per_img = np.stack([psnr_i, psnr_y_i], 1).astype(np.float64)
-            u8 = ddist.all_gather_results(u8_local, n_b, rank, world)           # the one collective of the path
+            u8 = ddist.all_gather_results(u8_local, n_b, rank, world, engine=eng)           # the one collective of the path
             allm = ddist.all_gather_results(torch.from_numpy(per_img.reshape(-1, 2)), n_b, rank, world).numpy()
             p, p_y = float(np.mean(allm[:, 0])), float(np.mean(allm[:, 1]))
             psnrs.append(p * n_b)

@@ -214,6 +214,19 @@ typedef struct dpir_loop_desc {
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
                   float* out_f32_dev, uint8_t* out_u8_dev);
 
+/* ---- multi-GPU: the one collective of the path ------------------------------ */
+/* One process and one engine per GPU; images are block-partitioned over ranks, no exchange inside the loop (the reference is
+ * single-GPU: main_ddpir.py:135 sets world_size and never uses it).  After a batch, ONE all-gather of the uint8 results over
+ * RCCL / xGMI, enqueued on the engine stream behind the loop.  librccl.so is bound at run time (dlopen).
+ *   dpir_comm_unique_id : rank 0 creates the 128-byte ncclUniqueId; the host side ships it to the other ranks;
+ *   dpir_comm_init      : ncclCommInitRank on this engine's device;
+ *   dpir_allgather_results(send [bytes_per_rank], recv [world * bytes_per_rank]) : ncclAllGather(ncclUint8);
+ *   dpir_comm_destroy   : also done by dpir_destroy. */
+int dpir_comm_unique_id(void* id128_out);
+int dpir_comm_init(dpir_engine* e, int world, int rank, const void* id128);
+int dpir_allgather_results(dpir_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+int dpir_comm_destroy(dpir_engine* e);
+
 /* ---- degradation synthesis and metrics: the steps either side of the loop ------------------ */
 /* Replaces CustomDataset.__getitem__'s arithmetic (main_ddpir.py:84-114) on the device.  gt_u8_dev: ground truth, uint8
  * [B,H,W,3] (what util.imread_uint returns).  deblur: scipy.ndimage.convolve(img_H, k, mode='wrap') on the uint8 image (float64

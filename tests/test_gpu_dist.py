@@ -56,3 +56,19 @@ def test_two_ranks_on_one_gpu_equal_one_rank(n, noise):
     mp.spawn(_run, args=(2, _free_port(), n, noise, two), nprocs=2, join=True)
     assert len(one[0]) == n * 32 * 32 * 3
     assert two[0] == one[0] and two[1] == one[0]
+
+
+def test_rccl_allgather_through_the_c_abi_world_1():
+    """dpir_comm_* / dpir_allgather_results bind ncclAllGather from librccl.so (dlopen).  One GPU admits one rank per
+    communicator, so this checks the binding, the stream ordering and the padding / slicing logic at world = 1."""
+    import torch
+    import diffpir_amd
+    from diffpir_amd import dist as ddist
+    eng = diffpir_amd.Engine(0)
+    try:
+        ddist.init_rccl(eng, 0, 1)
+        local = torch.randint(0, 256, (3, 8, 8, 3), dtype=torch.uint8, device="cuda:0")
+        out = ddist.all_gather_results(local, 3, 0, 1, engine=eng)
+        assert out.shape == local.shape and torch.equal(out, local) and out.data_ptr() != local.data_ptr()
+    finally:
+        eng.close()
