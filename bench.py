@@ -253,6 +253,24 @@ def main():
                    "k": np.repeat(synth.gaussian_psf(61, 3.0)[None, None], 64, 0)}
             prox["at_batch_64"] = {kk: v for kk, v in prox_roofline(eng, c64, 64, H, 1).items() if kk in ("achieved", "frac", "us_per_apply")}
 
+    # ---- the fused data step of the loop (eps -> x0 prologue + FFT prox + re-noise/Philox epilogue: 3 launches per step)
+    if extras and prox is not None and args.task == "deblur":
+        def fft_class_ms(nfe):
+            c = restore.LoopConfig(task="deblur", iter_num=nfe, lambda_=7.0, zeta=0.3)
+            eng.prof_enable(True); eng.prof_reset()
+            restore.restore_batch(eng, c, y, k=k, noise_source="device", seed=1234, use_graph=False, out_f32=out_f32)
+            eng.sync()
+            ms = eng.prof_read()["fft_prox"][0]
+            eng.prof_enable(False)
+            return ms
+        fft_class_ms(4)
+        us = (fft_class_ms(24) - fft_class_ms(4)) / 20 * 1e3          # the difference removes pre_calculate (same prof class)
+        fb = B * (4 * 3 * H * H * 4 + 3 * H * (H // 2 + 1) * 8 + H * (H // 2 + 1) * 4)     # x, eps, x (again), x' + FBFy + F2B
+        prox["fused_data_step"] = {"what": "one loop step's data side: x0 = clamp(c1 x - c2 eps) in the row-FFT prologue, spectral solve, "
+                                           "re-noise + Philox in the inverse row-FFT epilogue; x0 / noise never touch HBM",
+                                   "us_per_step": round(us, 2), "algorithmic_bytes": int(fb), "achieved": round(fb / (us * 1e-6) / 1e12, 4),
+                                   "frac": round(fb / (us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4), "launches_per_step": 3}
+
     # ---- secondary measurement in the other precision mode (same inputs, same graph path)
     alt = None
     if extras and not args.no_alt:

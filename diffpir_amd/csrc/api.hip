@@ -607,6 +607,23 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
     }
     hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
     DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
+    // FFT data step on the half-spectrum path, fused into three launches: eps -> clamped x0 in the row-FFT prologue, spectral
+    // solve between the column FFTs, re-noise (+ Philox) in the inverse row-FFT epilogue.  x0 is never materialised.
+    if (!last && d.generate_mode == 0 && (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && prox->half && d.guidance == 1.0f) {
+        if (with_n1 && d.noise_n1_dev && !d.noise_n2_dev) return invalid("host n1 noise requires host n2 noise");
+        const float2* tw = nullptr;
+        DPIR_TRY(e->fft2_table(prox->W, &tw));
+        float2* hbuf = nullptr;
+        DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)prox->B * 3 * prox->H * prox->WP, &hbuf));
+        ProfScope ps(&e->prof, PC_FFT);
+        DPIR_TRY(launch_rfft_rows(s, tw, b.x, 0.5f, 0.5f, 1.f, b.cur, hbuf, B * 3, W, b.out6, e->net.desc.out_channels));
+        SolveArgs sa{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur};
+        DPIR_TRY(launch_cfft_cols(s, tw, hbuf, sa, true, B * 3, H));
+        RenoiseArgs ra{b.x, b.cur, b.lp, d.noise_n1_dev, d.noise_n2_dev, d.noise_n2_dev ? total : 0, with_n1 ? 1 : 0};
+        DPIR_TRY(launch_irfft_rows(s, tw, hbuf, b.x0, 1.0f / ((float)H * (float)W), 2.f, -1.f, nullptr, 1.f, B * 3, W, &ra));
+        DPIR_HIP(hipGetLastError());
+        return Status{};
+    }
     {
         ProfScope ps(&e->prof, PC_ELEM);
         DPIR_TRY(launch_xstart(s, b.x, b.out6, e->net.desc.out_channels, 0.f, 0.f, b.x0, B, H * W, b.cur));

@@ -83,10 +83,14 @@ Status launch_precalc_finish(hipStream_t s, const float2* FB, float2* FBFy_inout
 // fft2.hip: half-spectrum register FFT path (sf = 1, N = 64 / 256).  twN = W_N^m table (N entries, device)
 bool fft2_supported(int H, int W, int sf);
 int fft2_padded_width(int W);
+// eps6 != null (loop only): the row source is x0 = clamp(c1 x - c2 eps) computed on the fly from x and the UNet output
 Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
-                        float2* out, int P, int N);
+                        float2* out, int P, int N, const float* eps6 = nullptr, int out_ch = 0);
+// fused re-noise epilogue of the inverse row pass (loop only): x_t <- renoise(x_t, x0'), noise host-fed (n2 [, n1] + step stride,
+// pointers re-read from lp when given) or Philox (n2 == null; seed / image offset from lp)
+struct RenoiseArgs { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
 Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
-                         const float* blend, float g, int P, int N);
+                         const float* blend, float g, int P, int N, const RenoiseArgs* ra = nullptr);
 Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N);
 Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw);
 Status launch_psf_embed_real(hipStream_t s, const float* k, int kh, int kw, float* out, int B, int H, int W);

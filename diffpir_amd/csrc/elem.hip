@@ -8,6 +8,7 @@
 // IBP prox (main_ddpir.py:401-406), torch bicubic interpolate (main_ddpir.py:295), torch.randn_like.
 #include "common.h"
 #include "elem.h"
+#include "philox.h"
 
 namespace dpir {
 
@@ -242,16 +243,7 @@ Status launch_bicubic_up(hipStream_t s, const float* in, float* out, int P, int 
     return Status{};
 }
 
-// ---------------------------------------------------------------- Philox4x32-10 + Box-Muller
-__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
-    const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
-    uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
-    uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
-    uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
-    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-}
-__device__ __forceinline__ float u01(uint32_t v) { return ((float)(v >> 8) + 0.5f) * (1.0f / 16777216.0f); }
-
+// ---------------------------------------------------------------- Philox4x32-10 + Box-Muller (philox.h)
 // one thread produces 4 normals for elements [4j, 4j+4) of image (image_offset + n); counter = (j, image, stream)
 __global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int64_t image_offset, size_t per_image, size_t total4,
                              const StepDev* sp, const LoopDev* lp) {
@@ -261,19 +253,8 @@ __global__ void randn_kernel(float* out, uint64_t seed, uint64_t stream_id, int6
     GRID_STRIDE(i, total4) {
         size_t q = (per_image + 3) / 4;
         size_t n = i / q, j = i - n * q;
-        uint64_t img = (uint64_t)(image_offset + (int64_t)n);
-        uint32_t c0 = (uint32_t)j, c1 = (uint32_t)img, c2 = (uint32_t)stream_id, c3 = (uint32_t)((img >> 32) ^ (stream_id >> 32) << 16 ^ (uint64_t)(j >> 32));
-        uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            philox_round(c0, c1, c2, c3, k0, k1);
-            k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-        }
-        float u0 = u01(c0), u1 = u01(c1), u2 = u01(c2), u3 = u01(c3);
-        float r0 = sqrtf(-2.0f * logf(u0)), r1 = sqrtf(-2.0f * logf(u2));
         float z[4];
-        z[0] = r0 * cospif(2.0f * u1); z[1] = r0 * sinpif(2.0f * u1);
-        z[2] = r1 * cospif(2.0f * u3); z[3] = r1 * sinpif(2.0f * u3);
+        philox_normal4(seed, stream_id, (uint64_t)(image_offset + (int64_t)n), j, z);
         float* o = out + n * per_image + j * 4;
         for (int e = 0; e < 4; ++e)
             if (j * 4 + e < per_image) o[e] = z[e];

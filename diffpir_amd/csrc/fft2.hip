@@ -15,6 +15,7 @@
 // (3 x 256 x 144 x 8 B = 0.88 MB, written once and read once by each neighbour kernel) stays in L2 / Infinity Cache.
 #include "common.h"
 #include "elem.h"
+#include "philox.h"
 
 namespace dpir {
 
@@ -102,9 +103,12 @@ __device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch,
 
 // ------------------------------------------------------------------------------------------------ rows forward
 // One slot = one PAIR of real rows.  grid: ceil(total_rows/2 / SLOTS); block 256 = SLOTS*R threads.
+// Fused loop prologue (dpir_run_loop): when `eps6` is given, the row loaded is not x but the denoiser's clamped x0 prediction
+// x0 = clamp(c1*x - c2*eps, -1, 1) (gaussian_diffusion.py:297,328-333), evaluated while staging -- x0 is never materialised.
+struct RowsFuse { const float* eps6; int out_ch; };
 template <int R, int THREADS>
 __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
-                                                         int WP, size_t total_rows, const float2* tw) {
+                                                         int WP, size_t total_rows, const float2* tw, RowsFuse fu) {
     constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;                                  // [N]
@@ -125,7 +129,17 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
             int r = i / V4, c4 = i - r * V4;
             size_t row = row0 + r;
             float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < total_rows) q = *reinterpret_cast<const float4*>(x + row * N + c4 * 4);
+            if (row < total_rows) {
+                q = *reinterpret_cast<const float4*>(x + row * N + c4 * 4);
+                if (fu.eps6) {
+#pragma clang fp contract(off)
+                    const size_t plane = row / N, n = plane / 3, c = plane - n * 3;
+                    const float4 e4 = *reinterpret_cast<const float4*>(fu.eps6 + ((n * fu.out_ch + c) * N + (row - plane * N)) * N + c4 * 4);
+                    const float c1 = sp->c1, c2 = sp->c2;
+                    q.x = fminf(fmaxf(c1 * q.x - c2 * e4.x, -1.0f), 1.0f); q.y = fminf(fmaxf(c1 * q.y - c2 * e4.y, -1.0f), 1.0f);
+                    q.z = fminf(fmaxf(c1 * q.z - c2 * e4.z, -1.0f), 1.0f); q.w = fminf(fmaxf(c1 * q.w - c2 * e4.w, -1.0f), 1.0f);
+                }
+            }
             *reinterpret_cast<float4*>(stage + r * (N + 4) + c4 * 4) = q;
         }
     }
@@ -160,9 +174,14 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
 }
 
 // ------------------------------------------------------------------------------------------------ rows inverse
+// Fused loop epilogue (dpir_run_loop): when `xt` is given, the value produced is x0' (the prox output in [-1,1]) and what is
+// STORED is the re-noised iterate (main_ddpir.py:451-456)
+//     eps = (x_t - sa_t x0') / s1m_t;   x = sa_p x0' + k1 (q eps + es n1) + k2 n2
+// written over x_t; n1 / n2 are host-fed tensors or Philox draws (same (seed, image, stream, counter) as randn_kernel).
+struct RenoiseFuse { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
 template <int R, int THREADS>
 __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
-                                                          const float* blend_base, float g, int WP, size_t total_rows, const float2* tw) {
+                                                          const float* blend_base, float g, int WP, size_t total_rows, const float2* tw, RenoiseFuse rn) {
     constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
@@ -208,6 +227,40 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
         if (blend_base) {
             float4 b0 = *reinterpret_cast<const float4*>(blend_base + gi);
             q.x = b0.x + g * (q.x - b0.x); q.y = b0.y + g * (q.y - b0.y); q.z = b0.z + g * (q.z - b0.z); q.w = b0.w + g * (q.w - b0.w);
+        }
+        if (rn.xt) {
+#pragma clang fp contract(off)
+            const StepDev st = *rn.sp;
+            const size_t per_image = (size_t)3 * N * N;
+            const size_t n = gi / per_image, e = gi - n * per_image;
+            float z1[4] = {0.f, 0.f, 0.f, 0.f}, z2[4];
+            if (rn.n2) {                         // host-fed noise: this batch's tensors, step i
+                const float4 t2 = *reinterpret_cast<const float4*>((rn.lp ? rn.lp->n2 : rn.n2) + (size_t)st.i * rn.stride + gi);
+                z2[0] = t2.x; z2[1] = t2.y; z2[2] = t2.z; z2[3] = t2.w;
+                if (rn.with_n1) {
+                    const float4 t1 = *reinterpret_cast<const float4*>((rn.lp ? rn.lp->n1 : rn.n1) + (size_t)st.i * rn.stride + gi);
+                    z1[0] = t1.x; z1[1] = t1.y; z1[2] = t1.z; z1[3] = t1.w;
+                }
+            } else {
+                const uint64_t img = (uint64_t)(rn.lp->image_offset + (long long)n);
+                philox_normal4(rn.lp->seed, 2 + 4 * (uint64_t)st.i, img, e >> 2, z2);
+                if (rn.with_n1) philox_normal4(rn.lp->seed, 1 + 4 * (uint64_t)st.i, img, e >> 2, z1);
+            }
+            const float4 xo = *reinterpret_cast<const float4*>(rn.xt + gi);
+            const float xv[4] = {xo.x, xo.y, xo.z, xo.w}, av[4] = {q.x, q.y, q.z, q.w};
+            float rv[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float a = av[u];
+                const float eps = (xv[u] - st.sa_t * a) / st.s1m_t;
+                float inner = st.q * eps;
+                if (rn.with_n1) inner = inner + st.es * z1[u];
+                float v = st.sa_p * a + st.k1 * inner;
+                v = v + st.k2 * z2[u];
+                rv[u] = v;
+            }
+            *reinterpret_cast<float4*>(rn.xt + gi) = make_float4(rv[0], rv[1], rv[2], rv[3]);
+            continue;
         }
         *reinterpret_cast<float4*>(out + gi) = q;
     }
@@ -292,25 +345,27 @@ static size_t cols_lds() { return (size_t)(R * R + (ColCfg<R>::THREADS / R) * (R
 
 template <int R>
 static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
-                          const float2* tw) {
+                          const float2* tw, RowsFuse fu) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
     auto fn = rfft_rows_kernel<R, ROW_THREADS>;
     static bool attr = false;
     if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw, fu);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
-                        float2* out, int P, int N) {
-    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN);
+                        float2* out, int P, int N, const float* eps6, int out_ch) {
+    if (eps6 && !sp) return invalid("rfft_rows: the fused x0 prologue reads its coefficients from the device step block");
+    const RowsFuse fu{eps6, out_ch};
+    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN, fu) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN, fu);
 }
 
 template <int R>
 static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
-                           int P, int N, const float2* tw) {
+                           int P, int N, const float2* tw, RenoiseFuse rn) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
@@ -318,14 +373,16 @@ static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float sc
     static bool attr = false;
     if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
     hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
-                       rows, tw);
+                       rows, tw, rn);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
-                         const float* blend, float g, int P, int N) {
-    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN)
-                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN);
+                         const float* blend, float g, int P, int N, const RenoiseArgs* ra) {
+    RenoiseFuse rn{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
+    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn)
+                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn);
 }
 
 template <int R, int MODE>
