@@ -54,12 +54,16 @@ def test_run_loop_matches_live_reference_fixture(engine, tiny, golden, name, kw,
                                 use_graph=graph).numpy()
     gt = golden("loops")["gt" if not name.startswith("sr") else "sr_gt"]
     if name in ("deblur", "deblur_eta", "sr_blur"):
-        # FFT prox: the bound follows the reference's own fp32 rounding noise (tests/gpu_common.py::fft_prox_parity); the
-        # yardstick run is the oracle, which reproduces the live-reference fixture bit for bit (tests/test_oracle_golden.py)
+        # FFT prox: the bound follows the reference's own fp32 rounding noise (tests/gpu_common.py::fft_prox_parity).  The
+        # yardstick is the oracle loop with the prox in float64 (`exact`), run here.  The fp32 oracle rerun (`oref`) equals the
+        # live-reference fixture bit for bit on the machine that generated it (tests/test_oracle_golden.py) but NOT on another
+        # CPU (different FFT / GEMM code paths: measured 2e-3..8e-3 on the MI355X box's host) -- the same ill-conditioning the
+        # gate is built around, so the rerun is held to the same floor as the engine rather than to bit equality.
         ocfg = do.LoopConfig(kw["task"], kw["iter_num"], 12.75 / 255, kw["lambda_"], kw["zeta"], eta=kw.get("eta", 0.0), sf=kw.get("sf", 1))
         _, sd = tiny
         oref, exact = oracle_pair("loops_" + name, sd, uo.tiny_hp(), ocfg, y, k, seed)
-        assert np.abs(oref - ref).max() < 2e-5
+        fl = ref - exact
+        assert np.sqrt(np.mean((oref - ref) ** 2)) <= 2.0 * np.sqrt(np.mean(fl * fl)) + 2e-5
         fft_prox_parity(out, ref, gt, f"{name} graph={graph}", exact=exact)
     else:
         assert np.abs(out - ref).max() < 2e-3
