@@ -16,70 +16,9 @@
 #include "common.h"
 #include "elem.h"
 #include "philox.h"
+#include "fft_regs.h"
 
 namespace dpir {
-
-__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
-__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
-__device__ __forceinline__ float2 cmul2(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
-__device__ __forceinline__ float2 cmulc2(float2 a, float2 b) { return make_float2(a.x * b.x + a.y * b.y, a.y * b.x - a.x * b.y); }  // a*conj(b)
-template <bool INV> __device__ __forceinline__ float2 mul_mi(float2 a) {   // a * (-i) forward, a * (+i) inverse
-    return INV ? make_float2(-a.y, a.x) : make_float2(a.y, -a.x);
-}
-
-template <bool INV> __device__ __forceinline__ void fft4(float2& a0, float2& a1, float2& a2, float2& a3) {
-    float2 s0 = cadd(a0, a2), s1 = csub(a0, a2), s2 = cadd(a1, a3), s3 = mul_mi<INV>(csub(a1, a3));
-    a0 = cadd(s0, s2); a2 = csub(s0, s2); a1 = cadd(s1, s3); a3 = csub(s1, s3);
-}
-template <bool INV> __device__ __forceinline__ void fft2p(float2& a0, float2& a1) {
-    float2 t = a0; a0 = cadd(t, a1); a1 = csub(t, a1);
-}
-
-// in-register R-point FFT, natural order in and out (R = 8 or 16)
-template <int R, bool INV> struct RegFFT;
-template <bool INV> struct RegFFT<16, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[16]) {
-        const float c1 = 0.92387953251128674f, s1 = 0.38268343236508977f, h = 0.70710678118654752f;
-        // step 1: 4-point FFTs over n1 for each n2 (x[4 n1 + n2])
-#pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) fft4<INV>(v[n2], v[4 + n2], v[8 + n2], v[12 + n2]);
-        // now v[4 k1 + n2] = t[k1][n2]; twiddle W16^(n2 k1) (conjugated for the inverse)
-        const float2 w[10] = {{1.f, 0.f}, {c1, -s1}, {h, -h}, {s1, -c1}, {0.f, -1.f}, {-s1, -c1}, {-h, -h}, {-c1, -s1}, {-1.f, 0.f}, {-c1, s1}};
-#pragma unroll
-        for (int k1 = 1; k1 < 4; ++k1)
-#pragma unroll
-            for (int n2 = 1; n2 < 4; ++n2) {
-                float2 tw = w[k1 * n2];
-                v[4 * k1 + n2] = INV ? cmulc2(v[4 * k1 + n2], tw) : cmul2(v[4 * k1 + n2], tw);
-            }
-        // step 2: 4-point FFTs over n2 for each k1 -> X[k1 + 4 k2] at position 4 k1 + k2
-#pragma unroll
-        for (int k1 = 0; k1 < 4; ++k1) fft4<INV>(v[4 * k1], v[4 * k1 + 1], v[4 * k1 + 2], v[4 * k1 + 3]);
-        // transpose 4x4 to natural order: out[k1 + 4 k2] <- v[4 k1 + k2]
-#pragma unroll
-        for (int a = 0; a < 4; ++a)
-#pragma unroll
-            for (int b = a + 1; b < 4; ++b) { float2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
-    }
-};
-template <bool INV> struct RegFFT<8, INV> {
-    static __device__ __forceinline__ void run(float2 (&v)[8]) {
-        const float h = 0.70710678118654752f;
-        // 8 = 2 x 4: n = 4 n1 + n2 (n1 < 2, n2 < 4), k = k1 + 2 k2
-#pragma unroll
-        for (int n2 = 0; n2 < 4; ++n2) fft2p<INV>(v[n2], v[4 + n2]);       // t[k1][n2] at v[4 k1 + n2]
-        const float2 w[4] = {{1.f, 0.f}, {h, -h}, {0.f, -1.f}, {-h, -h}};    // W8^(n2) for k1 = 1
-#pragma unroll
-        for (int n2 = 1; n2 < 4; ++n2) v[4 + n2] = INV ? cmulc2(v[4 + n2], w[n2]) : cmul2(v[4 + n2], w[n2]);
-        fft4<INV>(v[0], v[1], v[2], v[3]);                                  // X[0 + 2 k2] at v[k2]
-        fft4<INV>(v[4], v[5], v[6], v[7]);                                  // X[1 + 2 k2] at v[4 + k2]
-        float2 o[8];
-#pragma unroll
-        for (int k2 = 0; k2 < 4; ++k2) { o[2 * k2] = v[k2]; o[2 * k2 + 1] = v[4 + k2]; }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) v[i] = o[i];
-    }
-};
 
 // Two-pass N = R*R transform for one "slot" (R cooperating threads, t = 0..R-1).
 //   pass 1 in : thread t holds x[R n1 + t], n1 = 0..R-1            (stride-R elements, offset t)

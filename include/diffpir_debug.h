@@ -10,6 +10,16 @@ extern "C" {
  * mode 0 plain / 1 nearest-up source / 2 avg-pool source; with_prm: fused GroupNorm+SiLU prologue on/off. */
 int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int ks, int mode, int with_prm,
                           int dbg, int iters, double* ms_out);
+/* Concurrency probe: `blocks` workgroups of `threads` threads park a pattern in `lds_bytes` of LDS and in 32 registers per
+ * thread, wait `spin_ticks` of the 100 MHz wall clock, verify; *bad_out = LDS mismatches (low 32 bits) + register mismatches << 32. */
+int dpir_debug_victim(dpir_engine* e, int lds_bytes, int threads, int blocks, long long spin_ticks, int iters, unsigned long long* bad_out);
+/* ALU probe: threads run `iters_in_kernel` dependent exact-integer fp32 operations (mode 0 v_add_f32, 1 v_pk_add_f32, 2 v_pk_fma_f32,
+ * 3 v_pk_mul_f32) and check the closed-form result; *bad_out = number of threads whose result was wrong. */
+int dpir_debug_victim_alu(dpir_engine* e, int mode, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
+/* Register-FFT probe (csrc/dbg_fft.inc): same source built with (pk) and without (nopk) packed-fp32 instructions; *bad_out =
+ * threads whose two identical computations disagreed. */
+int dpir_debug_victim_fft_pk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
+int dpir_debug_victim_fft_nopk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
 #ifdef __cplusplus
 }
 #endif
