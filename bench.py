@@ -100,7 +100,7 @@ def conv_roofline(eng, B, H, precision, model_name):
     ms, cnt = prof["conv3x3"]
     fl = eng.unet_flops(H, H, 0) * B * n_pass
     achieved = fl / (ms * 1e-3) / 1e12
-    peak = PEAK_FP32_MFMA_TFLOPS if precision == "f32" else PEAK_F16X3_TFLOPS
+    peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x1": 2500.0}.get(precision, PEAK_F16X3_TFLOPS)
     kern = ("conv2_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32, exact fp32)" if precision == "f32" else
             "conv6_mfma_kernel<3x3> (3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split*_kernel; "
             "two workgroups per CU)")
@@ -272,10 +272,8 @@ def main():
                                    "us_per_step": round(us, 2), "algorithmic_bytes": int(fb), "achieved": round(fb / (us * 1e-6) / 1e12, 4),
                                    "frac": round(fb / (us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4), "launches_per_step": 3}
 
-    # ---- secondary measurement in the other precision mode (same inputs, same graph path)
-    alt = None
-    if extras and not args.no_alt:
-        other = "f16x3" if args.precision == "f32" else "f32"
+    # ---- secondary measurements in the other arithmetic modes (same inputs, weights, device noise and graph path)
+    def other_mode(other):
         eng2 = load(args.model, other)
         y2 = eng2.to_device(case["y"]); k2 = None if case["k"] is None else eng2.to_device(case["k"])
         m2 = None if case["mask"] is None else eng2.to_device(case["mask"])
@@ -291,15 +289,24 @@ def main():
         tb = time.perf_counter() - ta
         a_out, b_out = headline_out, o2.numpy()
         gt = case["gt"] * 2 - 1
+        pa, pb = restore.psnr_batch(a_out * 2 - 1, gt), restore.psnr_batch(b_out * 2 - 1, gt)
         rf2 = conv_roofline(eng2, B, H, other, args.model)
-        alt = {"precision": other, "value": round(B / tb, 4), "unit": "images/s", "ms_per_step": round(tb * 1e3, 2),
-               "max_abs_diff_vs_headline_output": float(np.abs(a_out - b_out).max()),
-               "psnr_headline_dB": round(restore.psnr_batch(a_out * 2 - 1, gt), 5),
-               "psnr_alt_dB": round(restore.psnr_batch(b_out * 2 - 1, gt), 5),
-               "roofline_frac": rf2["frac"], "unet_step_frac": rf2["unet_step_frac"], "peak": rf2["peak"],
-               "note": "exact-fp32 MFMA kernels on the same inputs, weights and device noise; parity of BOTH modes with the "
-                       "reference is what tests/ -m gpu assert -- this entry only shows that the two modes agree"}
         eng2.close()
+        return {"precision": other, "value": round(B / tb, 4), "unit": "images/s", "ms_per_step": round(tb * 1e3, 2),
+                "max_abs_diff_vs_headline_output": float(np.abs(a_out - b_out).max()),
+                "psnr_headline_dB": round(pa, 5), "psnr_alt_dB": round(pb, 5), "abs_dpsnr_dB": round(abs(pa - pb), 6),
+                "roofline_frac": rf2["frac"], "unet_step_frac": rf2["unet_step_frac"], "peak": rf2["peak"]}
+    alt = reduced = None
+    if extras and not args.no_alt:
+        alt = other_mode("f16x3" if args.precision == "f32" else "f32")
+        alt["note"] = ("exact-fp32 MFMA kernels on the same inputs, weights and device noise; parity of BOTH modes with the "
+                       "reference is what tests/ -m gpu assert -- this entry only shows that the two modes agree")
+        # the opt-in reduced-precision mode (f16 operands, ONE MFMA per product, fp32 accumulate, fp32 GroupNorm /
+        # softmax -- the reference's own use_fp16 recipe).  NOT the headline: it does not meet the fp32 parity bar layer by layer
+        # (8.7e-4 relative per forward); its quality contract is the measured PSNR change, reported here.
+        reduced = other_mode("f16x1")
+        reduced["note"] = ("opt-in engine_precision: f16x1 (set_precision('f16x1')); roofline fractions against the dense f16 MFMA peak; "
+                           "quality contract = abs_dpsnr_dB against the fp32-equivalent headline run on the same inputs")
     eng_closed = False
 
     # ---- BASELINE configs[2]: ImageNet-256 topology, x4 SISR, B = 32, 100 NFE
@@ -342,7 +349,7 @@ def main():
                                        f"({'61x61 Gaussian PSF' if args.task == 'deblur' else args.task}), {args.nfe} NFE, "
                                        f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
                            "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results"},
-                "roofline": roofline, "roofline_prox": prox, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt}
+                "roofline": roofline, "roofline_prox": prox, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
         print(json.dumps(line))
     ddist.shutdown()
     if not eng_closed:
