@@ -27,7 +27,9 @@ def init(backend: str = "nccl"):
     backend "nccl" is RCCL over xGMI on ROCm; "gloo" (host staging) is what the single-GPU / CPU tests use."""
     import torch.distributed as dist
     rank, local_rank, world = env_rank_world()
-    if world > 1 and not dist.is_initialized():
+    # DIFFPIR_FORCE_DIST=1 joins the group at WORLD_SIZE == 1 too, so that the RCCL code path (init, barrier, all_gather,
+    # all_reduce) can be exercised on a single-GPU box exactly as the multi-GPU launch runs it (tests/test_gpu_dist.py)
+    if (world > 1 or os.environ.get("DIFFPIR_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -121,7 +123,7 @@ def all_gather_results(local, n_images: int, rank: int, world: int, engine=None)
         engine._check(engine.lib.dpir_allgather_results(engine.h, pad.data_ptr(), recv.data_ptr(), pad.numel() * pad.element_size()))
         engine.sync()
         return torch.cat([recv[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local
     sizes = [shard_range(n_images, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)

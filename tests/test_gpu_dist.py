@@ -72,3 +72,21 @@ def test_rccl_allgather_through_the_c_abi_world_1():
         assert out.shape == local.shape and torch.equal(out, local) and out.data_ptr() != local.data_ptr()
     finally:
         eng.close()
+
+
+def test_bench_launch_line_with_the_nccl_backend_world_1():
+    """The driver's multi-GPU launch line (`python -m torch.distributed.run ... bench.py --gpus N`) on the one GPU of this box:
+    DIFFPIR_FORCE_DIST=1 makes rank 0 join a 1-rank RCCL group, so process-group init, the barrier, the uint8 all-gather and the
+    MAX all-reduce of the timing run through backend "nccl" exactly as they do at N > 1."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIFFPIR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+           "--nfe", "6", "--batch", "4", "--no-cpu-baseline", "--no-c3", "--no-alt"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["global_batch"] == 4
