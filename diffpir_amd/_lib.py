@@ -114,6 +114,16 @@ def load():
         raise EngineLibraryError(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             f"or `make -C diffpir_amd/csrc`.  There is no CPU fallback.")
+    # One ROCm runtime per process.  The PyTorch wheel bundles its own libamdhip64 / libhsa-runtime64 / librccl; libdiffpir_hip.so
+    # links the same SONAMEs, so whichever is loaded FIRST serves both.  If this library came first (/opt/rocm's runtime) and
+    # torch later, torch's librccl would dlopen its own, never-initialised copy of the HSA runtime and RCCL init fails with
+    # "no ROCm-capable device is detected" (measured, tests/test_gpu_dist.py).  Every host flow here uses torch as plumbing
+    # (checkpoints, torch.distributed), so torch's runtime is loaded first when torch is installed; without torch the system
+    # ROCm under /opt/rocm serves the library and its RCCL binding alike.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     try:
         lib = C.CDLL(LIB_PATH)
     except OSError as ex:  # pragma: no cover
