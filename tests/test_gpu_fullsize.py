@@ -89,6 +89,19 @@ def test_c2_100_nfe_vs_oracle(ffhq):
     assert gap <= 1e-3 and err < 1e-3          # the early steps' rounding noise is gone by 100 NFE: a tight pixel bound holds
 
 
+def test_c4_motion_deblur_vs_oracle(ffhq):
+    """BASELINE config 4's per-GPU work: FFHQ topology, 256x256, a NON-symmetric 61x61 motion PSF per image (random-walk line; the
+    `motionblur` package is not available offline), through the replayed graph; 4 NFE at B = 2 against the oracle."""
+    e, sd, precision = ffhq
+    case = synth.make_case("deblur", 2, 256, 256, seed=11, ksize=61, blur="motion")
+    assert np.abs(case["k"][0, 0] - case["k"][0, 0, ::-1, ::-1]).max() > 1e-3          # really asymmetric
+    cfg = restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(64),
+                                use_graph=True).numpy()
+    ref, exact = oracle_pair("c4_motion_4nfe", sd, uo.ffhq_hp(), do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3), case["y"], case["k"], 64)
+    fft_prox_parity(out, ref, case["gt"], f"C4 motion deblur B=2 4-NFE [{precision}] vs oracle", exact=exact)
+
+
 @pytest.fixture(scope="module", params=PRECISIONS)
 def imagenet(request):
     e = diffpir_amd.Engine(0)
@@ -150,6 +163,18 @@ def test_imagenet512_class_conditional_forward(precision):
         assert err < TOL_LAYER
         with pytest.raises(diffpir_amd.EngineError):
             e.unet_forward(e.to_device(x.numpy()), t.numpy(), None)              # unet.py:643-645: y iff class-conditional
+        if precision == "f16x3":
+            # config 5 in miniature: 128^2 -> 512^2, x4 bicubic PSF, class label through the loop (model_kwargs), 2 NFE, graph on
+            import os
+            kb = np.load(os.path.join(os.path.dirname(__file__), "golden", "operators.npz"))["k_bic4"][None, None].astype(np.float32)
+            case = synth.make_case("sr", 1, 512, 512, seed=5, sf=4)
+            cfg = restore.LoopConfig(task="sr", iter_num=2, lambda_=6.0, zeta=0.25, sf=4)
+            lab = np.array([417])
+            o = restore.restore_batch(e, cfg, case["y"], k=kb, labels=lab, noise_source="host", noise_fn=seeded_noise_fn_np(65),
+                                      use_graph=True).numpy()
+            r, exact = oracle_pair("c5_sr4_2nfe", sd, hp, do.LoopConfig("sr", 2, 12.75 / 255, 6.0, 0.25, sf=4), case["y"], kb, 65,
+                                   y_label=torch.from_numpy(lab))
+            fft_prox_parity(o, r, case["gt"], "C5 512^2 class-cond sr x4 2-NFE [f16x3] vs oracle", exact=exact)
     finally:
         e.close()
 
