@@ -33,4 +33,4 @@ eng.sync()
 prof = eng.prof_read(); eng.prof_enable(False)
 fl = eng.unet_flops(H, H) * B
 cls = {k: round(v[0] / 3, 3) for k, v in prof.items() if v[1]}
-print(f"{os.environ.get('DIFFPIR_LIB', 'default'):40s} fwd {wall:7.3f} ms  {fl / wall / 1e9:6.1f} TF/s  frac833 {fl / wall / 1e9 / 833.3:5.3f} | {cls}")
+print(f"{os.environ.get('RUN_LABEL', os.environ.get('DIFFPIR_LIB', 'default')):40s} fwd {wall:7.3f} ms  {fl / wall / 1e9:6.1f} TF/s  frac833 {fl / wall / 1e9 / 833.3:5.3f} | {cls}")
