@@ -134,7 +134,7 @@ def main(argv=None):
         import subprocess
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={num_gpus}", "--master-addr", "127.0.0.1",
                "--master-port", os.environ.get("MASTER_PORT", "29541"), "-m", "diffpir_amd.main_ddpir"] + list(argv if argv is not None else sys.argv[1:])
-        return subprocess.call(cmd)
+        return subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")))
     from . import dist as ddist
     rank, local_rank, world = ddist.init(args.dist_backend)
     np.random.seed(config.seed)
