@@ -190,6 +190,11 @@ def main():
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # test hooks (tests/test_gpu_dist.py runs the N = 2 launch line on a ONE-GPU box): all ranks on one device, gloo instead of RCCL
+    # (RCCL refuses two ranks on one GPU).  Never set by the driver.
+    if "DIFFPIR_BENCH_DEVICE" in os.environ:
+        local_rank = int(os.environ["DIFFPIR_BENCH_DEVICE"])
+    backend = os.environ.get("DIFFPIR_BENCH_BACKEND", "nccl")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -197,7 +202,7 @@ def main():
     import diffpir_amd
     from diffpir_amd import restore, synth, script_util, weights, dist as ddist
     torch.cuda.set_device(local_rank)
-    ddist.init("nccl")          # RCCL over xGMI; a no-op at WORLD_SIZE == 1
+    ddist.init(backend)         # "nccl" = RCCL over xGMI; a no-op at WORLD_SIZE == 1
 
     def load(model_name, precision):
         e = diffpir_amd.Engine(local_rank)
@@ -240,7 +245,7 @@ def main():
     for _ in range(args.steps):
         one_step()
     fence()
-    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device=f"cuda:{local_rank}")
+    elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device=None if backend == "gloo" else f"cuda:{local_rank}")
     value = B * world * args.steps / elapsed
     headline_out = out_f32.numpy()           # before the instrumented passes below reuse the buffer
 

@@ -90,3 +90,23 @@ def test_bench_launch_line_with_the_nccl_backend_world_1():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["global_batch"] == 4
+
+
+def test_bench_launch_line_two_ranks_on_one_gpu_gloo():
+    """The N = 2 launch line with both ranks on the one GPU of this box (gloo: RCCL refuses two ranks per GPU): every rank > 0 code
+    path of bench.py -- sharded image offsets, the padded all-gather, MAX over ranks, rank 0 printing the one JSON line."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DIFFPIR_BENCH_BACKEND="gloo", DIFFPIR_BENCH_DEVICE="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+           "--nfe", "6", "--batch", "2"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
+    assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
