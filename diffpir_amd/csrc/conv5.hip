@@ -154,27 +154,43 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
         const unsigned long long m = __ballot(bad);
         if (m != 0ull && p.range_ctr && lane == __builtin_ctzll(m)) atomicAdd(p.range_ctr, (unsigned long long)__builtin_popcountll(m));
     }
-    // ---- epilogue: un-scale, bias (+ residual), 128-byte coalesced NCHW stores
+    // ---- epilogue: un-scale, bias (+ residual), NCHW stores.  The accumulator layout (lanes = pixels, registers = output
+    // channels) would give 4-byte-per-lane stores: 128 store instructions per wave for its 128 co x 64 px, and the per-CU store
+    // issue rate, not HBM, then bounds these short-K kernels.  Each 32-channel block is therefore transposed through a
+    // wave-private LDS slab (the operand buffers are free) so that a lane owns 4 consecutive pixels of one channel:
+    // 32 float4 stores per wave, each instruction writing four 256-byte runs.
+    __syncthreads();                                   // every wave is done reading the operand buffers
+    constexpr int SROW = 68;                           // slab row: 64 pixels + 4 floats of padding (16-byte aligned rows)
+    float* slab = reinterpret_cast<float*>(smem5) + wave * (32 * SROW);
+    const int row_l = lane >> 4, c4 = lane & 15;
+    const long long g4 = px0 + wave * 64 + 4 * c4;     // HW % 4 == 0 (conv5_supported): the 4 pixels share an image
+    const bool ok4 = g4 < p.total_px;
+    const int n4 = ok4 ? (int)(g4 / HW) : 0;
+    const size_t base4 = (size_t)n4 * p.Cout * HW + (size_t)(g4 - (long long)n4 * HW);
     const int co0 = co_blk * 128;
 #pragma unroll
-    for (int j = 0; j < WPX; ++j) {
-        const long long g = px0 + pxl[j];
-        if (g >= p.total_px) continue;
-        const int n = pn[j];
-        const int pp = (int)(g - (long long)n * HW);
-        const size_t base = (size_t)n * p.Cout * HW + pp;
+    for (int i = 0; i < WCO; ++i) {
 #pragma unroll
-        for (int i = 0; i < WCO; ++i)
+        for (int j = 0; j < WPX; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int co = co0 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                if (co < p.Cout) {
-                    float v = acc[i][j][r] * p.out_scale + p.bias[co];
-                    const size_t o = base + (size_t)co * HW;
-                    if (p.res) v = p.res[o] + v;
-                    p.out[o] = v;
+            for (int r = 0; r < 16; ++r)
+                slab[((r & 3) + 8 * (r >> 2) + 4 * half) * SROW + j * 32 + l31] = acc[i][j][r];
+#pragma unroll
+        for (int ps = 0; ps < 8; ++ps) {
+            const int row = ps * 4 + row_l;
+            const int co = co0 + i * 32 + row;
+            const float4 a4 = *reinterpret_cast<const float4*>(slab + row * SROW + 4 * c4);
+            if (ok4 && co < p.Cout) {
+                const float bz = p.bias[co];
+                float4 v = make_float4(a4.x * p.out_scale + bz, a4.y * p.out_scale + bz, a4.z * p.out_scale + bz, a4.w * p.out_scale + bz);
+                const size_t o = base4 + (size_t)co * HW;
+                if (p.res) {
+                    const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
+                    v = make_float4(rr.x + v.x, rr.y + v.y, rr.z + v.z, rr.w + v.w);
                 }
+                *reinterpret_cast<float4*>(p.out + o) = v;
             }
+        }
     }
 }
 
