@@ -69,6 +69,11 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.dpir_version() == 1
+    # the development-only header (probes and the isolated conv bench; not part of the drop-in boundary) must resolve as well
+    dbg = open(os.path.join(ROOT, "include", "diffpir_debug.h")).read()
+    dbg_syms = set(re.findall(r"\b(dpir_debug_[a-z0-9_]+)\s*\(", dbg))
+    assert len(dbg_syms) >= 5
+    assert not [n for n in sorted(dbg_syms) if not hasattr(lib, n)]
 
 
 def test_struct_layouts_match_header():
