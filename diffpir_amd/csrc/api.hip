@@ -564,7 +564,8 @@ int dpir_metrics(dpir_engine* e, const float* x0, const uint8_t* gt, int B, int 
 
 // ------------------------------------------------------------------------------------------ whole loop
 namespace {
-struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; StepDev *steps_dev, *cur; LoopDev* lp; };
+struct LoopBufs { float *x, *x0, *out6, *n1, *n2, *init_src; int *t_dev, *y_dev; StepDev *steps_dev, *cur; LoopDev* lp;
+                  float* film; };   // film: hoisted FiLM table [n_steps][film_rows] (class-unconditional models) or null
 
 __global__ void fill_t_kernel(int* p, const StepDev* sp, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,8 +606,8 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         if (!nr) { DPIR_TRY(launch_randn(s, b.n1, d.seed, 3, d.image_offset, B, (size_t)3 * H * W, b.cur, b.lp)); nr = b.n1; rstride = 0; }
         DPIR_TRY(launch_repaint_mix(s, b.x, d.y_dev, d.mask_dev, nr, 0.f, 0.f, total, b.cur, rstride, b.lp));
     }
-    hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
-    DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W));
+    if (!b.film) hipLaunchKernelGGL(fill_t_kernel, dim3((B + 255) / 256), dim3(256), 0, s, b.t_dev, b.cur, B);
+    DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W, b.film, b.film ? b.cur : nullptr));
     // FFT data step on the half-spectrum path, fused into three launches: eps -> clamped x0 in the row-FFT prologue, spectral
     // solve between the column FFTs, re-noise (+ Philox) in the inverse row-FFT epilogue.  x0 is never materialised.
     if (!last && d.generate_mode == 0 && (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && prox->half && d.guidance == 1.0f) {
@@ -706,6 +707,8 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     API_TRY(e, e->ws.getT("loop#cur", (size_t)1, &b.cur));
     API_TRY(e, e->ws.getT("loop#lp", (size_t)1, &b.lp));
     API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
+    const bool hoist_film = e->net.desc.num_classes == 0;
+    if (hoist_film) API_TRY(e, e->ws.getT("loop#film", (size_t)n_steps * e->net.film_rows, &b.film));
     bool need_prox = d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR;
     ProxState& prox = e->loop_prox;
     // sf decides the spectrum layout (half-spectrum register FFT vs bit-reversed c2c): a change of sf re-allocates too
@@ -735,6 +738,13 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     }
     if (with_n1 && d.noise_n2_dev && !d.noise_n1_dev) return fail(e, invalid("dpir_run_loop: eta != 0 with host noise needs noise_n1_dev"));
 
+    if (b.film) {   // time embedding + every ResBlock's FiLM projection for all steps, once per batch (batch-uniform timestep)
+        std::vector<int64_t> ts(n_steps);
+        for (int i = 0; i < n_steps; ++i) ts[i] = steps[i].t;
+        int* ts_dev = nullptr;
+        API_TRY(e, upload_ints(e, "loop#ts", ts.data(), n_steps, &ts_dev));
+        API_TRY(e, unet_film_table(e, ts_dev, n_steps, b.film));
+    }
     API_TRY(e, loop_init(e, d, b, &prox));
     hipGraphExec_t g_step = nullptr, g_last = nullptr;
     for (int i = 0; i < n_steps; ++i) {

@@ -120,6 +120,26 @@ struct CatSrc { const float* a; int ca; const float* b; int cb; };
 // lo == nullptr: single-product mode, only the hi plane is produced
 Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, int B, int H, int W, void* hi, void* lo,
                         unsigned long long* range_ctr = nullptr);
+// A split-K convolution whose slabs have not been combined yet (launch_conv6 with defer = true): value = sum_k partial[k]
+// (slab order) + bias + residual.  Either gn_act_small (the fused low-resolution prologue of the consumer) or
+// launch_conv6_resolve finishes it into `out`.
+struct PendingConv {
+    const float* partial = nullptr; int ksplit = 0; const float* bias = nullptr;
+    const float* res = nullptr; int res_mode = 0; float* out = nullptr; int B = 0, Cout = 0, H = 0, W = 0;
+    double2* stat_plane = nullptr;      // where the combine kernel would put the per-plane fp64 GroupNorm sums
+};
+// act.hip: fused low-resolution elementwise chain [split-K combine +] GroupNorm statistics + affine/FiLM fold + SiLU + resample +
+// f16 split, one workgroup per (image, group); src tensors at Hs x Ws, planes at the conv's output resolution
+struct StepDev;
+struct GnActArgs {
+    CatSrc src; PendingConv pend;
+    const float* gamma = nullptr; const float* beta = nullptr;
+    const float* film = nullptr; int film_stride = 0; int film_off = 0; const StepDev* fstep = nullptr; int frows = 0;
+    bool silu = true; int mode = 0; int B = 0, Hs = 0, Ws = 0;
+    void* hi = nullptr; void* lo = nullptr; unsigned long long* range_ctr = nullptr;
+};
+bool gn_act_small_supported(int C, int Hs, int Ws, int mode);
+Status launch_gn_act_small(hipStream_t s, const GnActArgs& a);
 // conv6.hip: 3x3, f16x3 (or f16x1), two workgroups per CU (private weight rings)
 struct Conv6Args {
     const void* xhi = nullptr; const void* xlo = nullptr;
@@ -133,7 +153,10 @@ struct Conv6Args {
 };
 bool conv6_supported(int H, int W);
 int conv6_stat_slots(int H, int W);
-Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out = nullptr);
+// pend_out != null: a split-K launch leaves its slabs uncombined and describes them in *pend_out (stat kind 3); the caller must
+// have them finished (gn_act_small or launch_conv6_resolve) before the slab buffer is reused
+Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out = nullptr, PendingConv* pend_out = nullptr);
+Status launch_conv6_resolve(hipStream_t s, const PendingConv& p);
 float pack_weights_conv6(const float* w_oihw, int cout, int cin, std::vector<uint16_t>& out);
 // conv5.hip: 1x1 convolution, f16x3 with the operand split done in-kernel from the fp32 NCHW (virtual concat) input
 struct Conv5Args {
@@ -153,9 +176,12 @@ Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part);
 // gn_stats partials [B][c] (double2)
 struct GnStatSrc { const float2* slots = nullptr; int nslots = 0; const double2* part = nullptr; int c = 0; };
 // prm[n*C+c] = {mean, rstd*gamma*(1+scale), beta*(1+scale)+shift, silu?1:0}; film = [B, film_stride] rows with
-// scale at film[n*film_stride + film_off + c], shift at +C; film == null -> plain GroupNorm
+// scale at film[n*film_stride + film_off + c], shift at +C; film == null -> plain GroupNorm.
+// fstep != null: film is the hoisted table [n_steps][frows] of dpir_run_loop; the row of the current step (fstep->i, read on
+// the device) is used for every image (film_stride = 0)
 Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
-                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm);
+                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm,
+                     const StepDev* fstep = nullptr, int frows = 0);
 // time embedding MLP: t_dev [B] int32 -> semb [B, ted] = silu(time_embed(timestep_embedding(t)) + label_emb[y])
 Status launch_time_embed(hipStream_t s, const int* t_dev, const int* y_dev, const float* freqs, const float* w0, const float* b0,
                          const float* w2, const float* b2, const float* label_emb, int B, int mc, float* tmp, float* semb);

@@ -510,8 +510,17 @@ static Status launch6(hipStream_t s, Conv6K k, int blocks) {
 }
 
 // stat_kind_out: 0 none, 1 epilogue slots (a.stat filled, conv6_stat_slots entries per plane), 2 per-plane fp64 records (a.stat_plane)
-Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out) {
+Status launch_conv6_resolve(hipStream_t s, const PendingConv& p) {
+    const int planes = p.B * p.Cout;
+    hipLaunchKernelGGL(conv6_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, p.partial, p.ksplit, p.bias, p.res, p.res_mode, p.out,
+                       p.Cout, p.H, p.W, planes, p.stat_plane);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, PendingConv* pend_out) {
     if (stat_kind_out) *stat_kind_out = 0;
+    if (pend_out) *pend_out = PendingConv{};
     const int geo = conv6_geo(a.H, a.W);
     if (geo < 0) return Status{DPIR_ERR_UNSUPPORTED, "conv6: shape not tiled"};
     Conv6K k;
@@ -557,10 +566,16 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out) {
     else if (geo == 1) DPIR_TRY((launch6<1, 4, false>(s, k, blocks * S)));
     else DPIR_TRY((launch6<2, 3, false>(s, k, blocks * S)));
     if (S > 1) {
-        const int planes = k.B * k.Cout;
-        hipLaunchKernelGGL(conv6_reduce_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, s, k.partial, S, k.bias, k.res, k.res_mode, k.out,
-                           k.Cout, k.H, k.W, planes, a.stat_plane);
-        if (a.stat_plane && stat_kind_out) *stat_kind_out = 2;
+        PendingConv pc;
+        pc.partial = k.partial; pc.ksplit = S; pc.bias = k.bias; pc.res = k.res; pc.res_mode = k.res_mode; pc.out = k.out;
+        pc.B = k.B; pc.Cout = k.Cout; pc.H = k.H; pc.W = k.W; pc.stat_plane = a.stat_plane;
+        if (pend_out) {
+            *pend_out = pc;
+            if (stat_kind_out) *stat_kind_out = 3;
+        } else {
+            DPIR_TRY(launch_conv6_resolve(s, pc));
+            if (a.stat_plane && stat_kind_out) *stat_kind_out = 2;
+        }
     }
     DPIR_HIP(hipGetLastError());
     return Status{};

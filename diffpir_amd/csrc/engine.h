@@ -116,6 +116,9 @@ namespace dpir {
 Status unet_load(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor* weights, int n);
 void unet_free(dpir_engine* e);
 // t_dev/y_dev: device int32 [B]
-Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W);
+// film_table / film_step: hoisted FiLM projections of a whole schedule (unet_film_table) and the device-resident current step
+Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W,
+                    const float* film_table = nullptr, const StepDev* film_step = nullptr);
+Status unet_film_table(dpir_engine* e, const int* t_dev, int n_steps, float* table);
 double unet_flops(const UNet& net, int H, int W, int cls = -1);
 }  // namespace dpir

@@ -8,6 +8,7 @@
 // folded into the consumer convolution's prologue (conv.hip) through the per-(image,channel)
 // parameter table written by gn_prm_kernel.
 #include "common.h"
+#include "elem.h"
 
 namespace dpir {
 
@@ -71,8 +72,11 @@ Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part) 
 // (float2 per 64-pixel wave) or gn_stats partials (double2 per plane), per source tensor of the virtual concat - in a
 // fixed order (thread-strided, then the usual wave/LDS tree), and writes the per-channel affine parameters.
 __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
-                                                     const float* film, int film_stride, int film_off, int C, float act, float4* prm) {
+                                                     const float* film, int film_stride, int film_off, int C, float act, float4* prm,
+                                                     const StepDev* fstep, int frows) {
     const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
+    // hoisted FiLM (dpir_run_loop): the projections of ALL steps were evaluated before the loop; row = current step, shared by the batch
+    if (film && fstep) film += (size_t)fstep->i * frows;
     const int cg = C / 32;
     double S = 0.0, SS = 0.0;
     for (int k = 0; k < cg; ++k) {
@@ -120,10 +124,11 @@ __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb,
 }
 
 Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
-                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm) {
+                     const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm,
+                     const StepDev* fstep, int frows) {
     if (C % 32 || sa.c + sb.c != C) return invalid("gn_prm: channel bookkeeping");
     hipLaunchKernelGGL(gn_prm_kernel, dim3(B * 32), dim3(256), 0, s, sa, sb, HW, gamma, beta, film, film_stride,
-                       film_off, C, silu ? 1.0f : 0.0f, prm);
+                       film_off, C, silu ? 1.0f : 0.0f, prm, fstep, frows);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -11,6 +11,7 @@
 #include <cstdint>
 #include <math.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace dpir {
 
@@ -269,16 +270,101 @@ struct Fwd {
     hipStream_t s;
     Workspace& ws;
     int B;
-    const float* film;     // [B, film_rows]
+    const float* film;     // [B, film_rows], or the hoisted table [n_steps, film_rows] when fstep != null
     int film_rows;
+    int film_stride;       // film_rows, or 0 for the hoisted table (one row per step, shared by the batch)
+    const StepDev* fstep;  // device-resident current step (row selector of the hoisted table) or null
     float* partial;        // split-K slab shared by all convolutions of the forward
     size_t partial_cap;
     // GroupNorm statistics already produced by the epilogue of the convolution that wrote a tensor (keyed by its address)
     struct FusedStat { const float2* slots; int nslots; const double2* part; };   // epilogue slots, or per-plane fp64 records (split-K combine)
     std::unordered_map<const float*, FusedStat> fused;
+    // The most recent 3x3 convolution if it ran split-K and its slabs are not combined yet: either the next layer's fused
+    // low-resolution prologue (gn_act_small) finishes it, or resolve() does -- before anything else reads the tensor or
+    // reuses the slab buffer.
+    PendingConv pending;
+    bool fuse_small;
+
+    Status resolve() {
+        if (!pending.partial) return Status{};
+        ProfScope ps(&e->prof, PC_CONV3);
+        DPIR_TRY(launch_conv6_resolve(s, pending));
+        if (pending.stat_plane) fused[pending.out] = FusedStat{nullptr, 0, pending.stat_plane};
+        else fused.erase(pending.out);
+        pending = PendingConv{};
+        return Status{};
+    }
+    bool is_pending(const float* p) const { return pending.partial && p && p == pending.out; }
+
+    // GroupNorm (+FiLM) + SiLU + 3x3 convolution.  Low-resolution layers on the f16 path take the fused prologue; everything
+    // else the separate statistics / gn_prm / act_split (or fp32 in-kernel prologue) route.
+    Status gn_conv(const GnW& g, const std::string& tag, int film_off, const ConvW& cw, const Act& in, int mode,
+                   const float* res, int res_mode, float* out, int Ho, int Wo) {
+        const int C = in.C();
+        const bool f16path = cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo);
+        if (fuse_small && f16path && C == g.c && C % 16 == 0 && gn_act_small_supported(C, in.H, in.W, mode)) {
+            const bool x1 = e->precision == 2;
+            int eh = mode == 1 ? Ho / 2 : (mode == 2 ? Ho * 2 : Ho), ew = mode == 1 ? Wo / 2 : (mode == 2 ? Wo * 2 : Wo);
+            if (eh != in.H || ew != in.W) return invalid("conv: source resolution does not match mode");
+            if (pending.partial && !is_pending(in.a)) DPIR_TRY(resolve());
+            if (is_pending(res)) return invalid("gn_conv: residual is an unfinished convolution");
+            const int C8 = 2 * ((C + 15) / 16);
+            const size_t plane = (size_t)B * C8 * Ho * Wo * 16;
+            char* s16 = nullptr;
+            DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
+            GnActArgs ga;
+            ga.src = CatSrc{in.a, in.ca, in.b, in.cb};
+            ga.pend = pending;
+            ga.gamma = g.gamma; ga.beta = g.beta;
+            ga.film = film_off >= 0 ? film : nullptr; ga.film_stride = film_stride; ga.film_off = film_off < 0 ? 0 : film_off;
+            ga.fstep = fstep; ga.frows = film_rows;
+            ga.silu = true; ga.mode = mode; ga.B = B; ga.Hs = in.H; ga.Ws = in.W;
+            ga.hi = s16; ga.lo = x1 ? nullptr : s16 + plane; ga.range_ctr = e->range_ctr;
+            {
+                ProfScope ps(&e->prof, PC_ELEM);
+                DPIR_TRY(launch_gn_act_small(s, ga));
+            }
+            if (pending.partial) { fused.erase(pending.out); pending = PendingConv{}; }   // finished (and stored) by the fused prologue
+            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo);
+        }
+        DPIR_TRY(resolve());
+        float4* prm = nullptr;
+        DPIR_TRY(gn(g, in, tag, film_off, true, &prm));
+        return conv(cw, in, mode, prm, res, res_mode, out, Ho, Wo);
+    }
+
+    Status conv6_on_planes(const ConvW& cw, char* s16, size_t plane, const float* res, int res_mode, float* out, int Ho, int Wo) {
+        const bool x1 = e->precision == 2;
+        Conv6Args a6;
+        a6.x1 = x1;
+        a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16; a6.w16_scale = cw.w16_scale;
+        a6.bias = cw.bias; a6.out = out; a6.res = res; a6.res_mode = res_mode;
+        a6.B = B; a6.Cin = cw.cin; a6.Cout = cw.cout; a6.H = Ho; a6.W = Wo;
+        a6.partial = partial; a6.partial_capacity = partial_cap;
+        const int slots = conv6_stat_slots(Ho, Wo);
+        float2* st = nullptr; double2* sp = nullptr;
+        if (slots > 0 && cw.cout % 32 == 0) {
+            const std::string key = std::to_string(reinterpret_cast<uintptr_t>(out));
+            DPIR_TRY(ws.getT("st#" + key, (size_t)B * cw.cout * slots, &st));
+            DPIR_TRY(ws.getT("sp#" + key, (size_t)B * cw.cout, &sp));
+        }
+        a6.stat = st; a6.stat_plane = sp;
+        int kind = 0;
+        PendingConv pc;
+        ProfScope ps(&e->prof, PC_CONV3);
+        DPIR_TRY(launch_conv6(s, a6, &kind, fuse_small ? &pc : nullptr));
+        if (kind == 1) fused[out] = FusedStat{st, slots, nullptr};
+        else if (kind == 2) fused[out] = FusedStat{nullptr, 0, sp};
+        else fused.erase(out);
+        if (kind == 3) pending = pc;
+        return Status{};
+    }
 
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
         const bool x1 = e->precision == 2;        // f16x1: single-product mode, hi halves only
+        // an unfinished split-K output is finished before anything but the fused prologue reads it (or reuses the slab buffer)
+        const bool use5 = cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo);   // no slab buffer
+        if (pending.partial && (is_pending(in.a) || is_pending(in.b) || is_pending(res) || !use5)) DPIR_TRY(resolve());
         if (cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo)) {
             // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
             // then conv6 (pure LDS-DMA + MFMA, two workgroups per CU); GroupNorm statistics of the output come out of its
@@ -294,29 +380,9 @@ struct Fwd {
                 ProfScope ps(&e->prof, PC_ELEM);
                 DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, x1 ? nullptr : s16 + plane, e->range_ctr));
             }
-            Conv6Args a6;
-            a6.x1 = x1;
-            a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16; a6.w16_scale = cw.w16_scale;
-            a6.bias = cw.bias; a6.out = out; a6.res = res; a6.res_mode = res_mode;
-            a6.B = B; a6.Cin = cw.cin; a6.Cout = cw.cout; a6.H = Ho; a6.W = Wo;
-            a6.partial = partial; a6.partial_capacity = partial_cap;
-            const int slots = conv6_stat_slots(Ho, Wo);
-            float2* st = nullptr; double2* sp = nullptr;
-            if (slots > 0 && cw.cout % 32 == 0) {
-                const std::string key = std::to_string(reinterpret_cast<uintptr_t>(out));
-                DPIR_TRY(ws.getT("st#" + key, (size_t)B * cw.cout * slots, &st));
-                DPIR_TRY(ws.getT("sp#" + key, (size_t)B * cw.cout, &sp));
-            }
-            a6.stat = st; a6.stat_plane = sp;
-            int kind = 0;
-            ProfScope ps(&e->prof, PC_CONV3);
-            DPIR_TRY(launch_conv6(s, a6, &kind));
-            if (kind == 1) fused[out] = FusedStat{st, slots, nullptr};
-            else if (kind == 2) fused[out] = FusedStat{nullptr, 0, sp};
-            else fused.erase(out);
-            return Status{};
+            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo);
         }
-        if (cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo)) {
+        if (use5) {
             Conv5Args a5;
             a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
             a5.bias = cw.bias; a5.out = out; a5.res = res; a5.B = B; a5.Cout = cw.cout; a5.H = Ho; a5.W = Wo;
@@ -337,6 +403,7 @@ struct Fwd {
     }
     Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out) {
         float4* prm = nullptr;
+        if (is_pending(in.a) || is_pending(in.b)) DPIR_TRY(resolve());
         DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * g.c, &prm));
         GnStatSrc src[2];
         const float* tp[2] = {in.a, in.b};
@@ -353,7 +420,7 @@ struct Fwd {
             src[k].part = part;
         }
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_gn_prm(s, src[0], src[1], in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_rows, film_off < 0 ? 0 : film_off, B, g.c, silu, prm));
+        DPIR_TRY(launch_gn_prm(s, src[0], src[1], in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_stride, film_off < 0 ? 0 : film_off, B, g.c, silu, prm, fstep, film_rows));
         *prm_out = prm;
         return Status{};
     }
@@ -367,14 +434,11 @@ struct Fwd {
         int Wo = r.mode == 1 ? in.W * 2 : (r.mode == 2 ? in.W / 2 : in.W);
         if (r.mode == 2 && ((in.H | in.W) & 1)) return invalid("resblock " + r.name + ": odd size cannot be average-pooled");
         size_t on = (size_t)B * r.cout * Ho * Wo;
-        float4* prm1 = nullptr; float4* prm2 = nullptr;
-        DPIR_TRY(gn(r.gn1, in, r.name + "#gn1", -1, true, &prm1));
         float* h1 = nullptr;
         DPIR_TRY(ws.getT(r.name + "#h1", on, &h1));
-        DPIR_TRY(conv(r.conv1, in, r.mode, prm1, nullptr, 0, h1, Ho, Wo));
+        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo));
         tap(r.name + "#h1", h1, on);
         Act h1a; h1a.a = h1; h1a.ca = r.cout; h1a.H = Ho; h1a.W = Wo;
-        DPIR_TRY(gn(r.gn2, h1a, r.name + "#gn2", r.film_off, true, &prm2));
         const float* res = nullptr; int res_mode = 0;
         if (r.has_skip) {
             float* sk = nullptr;
@@ -387,7 +451,7 @@ struct Fwd {
         }
         float* o = nullptr;
         DPIR_TRY(ws.getT(r.name + "#out", on, &o));
-        DPIR_TRY(conv(r.conv2, h1a, 0, prm2, res, res_mode, o, Ho, Wo));
+        DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, res, res_mode, o, Ho, Wo));
         tap(r.name, o, on);
         out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
         return Status{};
@@ -397,6 +461,7 @@ struct Fwd {
         if (in.b || in.ca != aw.c) return invalid("attention " + aw.name + ": bad input");
         int T = in.H * in.W;
         float4* prm = nullptr;
+        DPIR_TRY(resolve());
         DPIR_TRY(gn(aw.norm, in, aw.name + "#norm", -1, false, &prm));
         float *qkv = nullptr, *att = nullptr, *o = nullptr;
         DPIR_TRY(ws.getT(aw.name + "#qkv", (size_t)B * 3 * aw.c * T, &qkv));
@@ -431,7 +496,24 @@ struct Fwd {
 };
 }  // namespace
 
-Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W) {
+// All FiLM projections of a schedule at once (unet.py:199-205, 471-475): the timestep is uniform over the
+// batch, so emb -> emb_layers of every ResBlock depends on the step only.  table[i, :] = rows of step i (t_dev[i]).
+Status unet_film_table(dpir_engine* e, const int* t_dev, int n_steps, float* table) {
+    UNet& net = e->net;
+    if (!net.loaded) return Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"};
+    if (net.desc.num_classes > 0) return invalid("FiLM hoisting needs a class-unconditional model");
+    const int mc = net.desc.model_channels, ted = 4 * mc;
+    float *tmp = nullptr, *semb = nullptr;
+    DPIR_TRY(e->ws.getT("embS#tmp", (size_t)n_steps * (mc + ted), &tmp));
+    DPIR_TRY(e->ws.getT("embS#semb", (size_t)n_steps * ted, &semb));
+    ProfScope ps(&e->prof, PC_ELEM);
+    DPIR_TRY(launch_time_embed(e->stream, t_dev, nullptr, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, nullptr, n_steps, mc, tmp, semb));
+    DPIR_TRY(launch_rows_gemv(e->stream, net.film_w, net.film_b, semb, n_steps, net.film_rows, ted, table));
+    return Status{};
+}
+
+Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W,
+                    const float* film_table, const StepDev* film_step) {
     UNet& net = e->net;
     if (!net.loaded) return Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"};
     if ((net.desc.num_classes > 0) != (y_dev != nullptr))
@@ -442,10 +524,12 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     ProfScope whole(&e->prof, PC_UNET);
     const int mc = net.desc.model_channels, ted = 4 * mc;
     float *tmp = nullptr, *semb = nullptr, *film = nullptr;
-    DPIR_TRY(ws.getT("emb#tmp", (size_t)B * (mc + ted), &tmp));
-    DPIR_TRY(ws.getT("emb#semb", (size_t)B * ted, &semb));
-    DPIR_TRY(ws.getT("emb#film", (size_t)B * net.film_rows, &film));
-    {
+    const bool hoisted = film_table != nullptr && film_step != nullptr;
+    if (hoisted && net.desc.num_classes > 0) return invalid("hoisted FiLM table with a class-conditional model");
+    if (!hoisted) {
+        DPIR_TRY(ws.getT("emb#tmp", (size_t)B * (mc + ted), &tmp));
+        DPIR_TRY(ws.getT("emb#semb", (size_t)B * ted, &semb));
+        DPIR_TRY(ws.getT("emb#film", (size_t)B * net.film_rows, &film));
         ProfScope ps(&e->prof, PC_ELEM);
         DPIR_TRY(launch_time_embed(s, t_dev, y_dev, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, net.label_emb, B, mc, tmp, semb));
         DPIR_TRY(launch_rows_gemv(s, net.film_w, net.film_b, semb, B, net.film_rows, ted, film));
@@ -454,7 +538,11 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     float* partial = nullptr;
     size_t partial_cap = (size_t)16 * 1024 * 1024;   // 64 MiB
     DPIR_TRY(ws.getT("conv#partial", partial_cap, &partial));
-    Fwd f{e, s, ws, B, film, net.film_rows, partial, partial_cap};
+    Fwd f{e, s, ws, B, hoisted ? film_table : film, net.film_rows, hoisted ? 0 : net.film_rows, hoisted ? film_step : nullptr, partial, partial_cap};
+    {
+        static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
+        f.fuse_small = fuse_env;
+    }
     if (e->collect_taps) e->taps.clear();
 
     std::vector<Act> hs;
@@ -488,9 +576,8 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         DPIR_TRY(f.run_block(net, net.out_blocks[i], cat, &o));
         h = o;
     }
-    float4* prm = nullptr;
-    DPIR_TRY(f.gn(net.out_gn, h, "out#gn", -1, true, &prm));
-    DPIR_TRY(f.conv(net.out_conv, h, 0, prm, nullptr, 0, out, H, W));
+    DPIR_TRY(f.gn_conv(net.out_gn, "out#gn", -1, net.out_conv, h, 0, nullptr, 0, out, H, W));
+    DPIR_TRY(f.resolve());
     f.tap("out", out, (size_t)B * net.desc.out_channels * H * W);
     return Status{};
 }

@@ -21,7 +21,7 @@ def mk():
 
 engines = []
 ref = None
-for L in [1, 2, 4]:
+for L in [int(v) for v in os.environ.get("LANES_LIST", "1,2,4").split(",")]:
     while len(engines) < L:
         engines.append(mk())
     n = B // L
