@@ -5,10 +5,13 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE full restoration (100 NFE: init -> 100 x (UNet -> FFT prox -> re-noise) -> u8 output) of one batch of
-synthetic 256x256 inputs per GPU -- BASELINE configs[1]: FFHQ topology, Gaussian deblur (61x61 PSF), B = 16 per GPU.
-Inputs (y, k) are resident in HBM before the timed region; the loop is a replayed per-step hipGraph with device-side
-Philox noise; with N > 1 the batch is sharded by image (weak scaling, no data-path collective) and the u8 results are
-all-gathered over RCCL inside the timed region (diffpir_amd.dist, the function the YAML driver uses).  Weights are synthetic.
+synthetic inputs per GPU.  Workload (--config): at N = 1 BASELINE configs[1] (c2: FFHQ topology, 256x256 Gaussian deblur, 61x61 PSF,
+B = 16); at N > 1 BASELINE's multi-GPU configs[3] (c4: FFHQ topology, motion deblur, B = 32 per GPU = 256 over 8 GPUs), or
+--config c5 (512x512 class-conditional topology, x4 SISR, B = 8 per GPU = 64 over 8).  Inputs (y, k) are resident in HBM before
+the timed region; the loop is a replayed per-step hipGraph with device-side Philox noise; with N > 1 the batch is sharded by image
+(weak scaling, no data-path collective) and the u8 results are all-gathered over RCCL -- bound through the C ABI
+(dpir_allgather_results), engine-owned buffers, engine stream -- inside the timed region (diffpir_amd.dist, the function the
+YAML driver uses).  Weights are synthetic.
 
 Rank 0 adds to the ONE JSON line (single-GPU runs; each part can be switched off):
   roofline       the dominant kernel class (3x3 convolutions): algorithmic FLOPs over the HIP-event duration of every
@@ -49,11 +52,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="images per GPU (weak scaling)")
+    ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"],
+                    help="BASELINE workload: c2 = configs[1] (default at --gpus 1), c4 = configs[3] (default at --gpus > 1), c5 = configs[4]; "
+                         "--batch / --size / --task / --model override single fields")
+    ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling)")
     ap.add_argument("--nfe", type=int, default=100)
-    ap.add_argument("--size", type=int, default=256)
-    ap.add_argument("--task", default="deblur", choices=["deblur", "inpaint", "sr"])
-    ap.add_argument("--model", default="ffhq", choices=["ffhq", "imagenet256"])
+    ap.add_argument("--size", type=int, default=None)
+    ap.add_argument("--task", default=None, choices=["deblur", "inpaint", "sr"])
+    ap.add_argument("--blur", default=None, choices=["gaussian", "motion"])
+    ap.add_argument("--model", default=None, choices=["ffhq", "imagenet256", "imagenet512"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the BASELINE configs[2] object")
@@ -64,12 +71,22 @@ def parse():
     ap.add_argument("--no-alt", action="store_true", help="skip the secondary measurement in the other precision mode")
     ap.add_argument("--cpu-threads", type=int, default=32, help="torch CPU threads for the oracle (all 256 host threads "
                     "oversubscribe MKL-DNN at B=1: 79 s/NFE measured vs ~1 s/NFE at 32)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    preset = {"c2": dict(model="ffhq", task="deblur", blur="gaussian", batch=16, size=256),
+              "c4": dict(model="ffhq", task="deblur", blur="motion", batch=32, size=256),
+              "c5": dict(model="imagenet512", task="sr", blur="gaussian", batch=8, size=512)}[a.config or ("c2" if a.gpus == 1 else "c4")]
+    a.preset = a.config or ("c2" if a.gpus == 1 else "c4")
+    a.exact_preset = all(getattr(a, kk) in (None, v) for kk, v in preset.items()) and a.nfe == 100
+    for kk, v in preset.items():
+        if getattr(a, kk) is None:
+            setattr(a, kk, v)
+    return a
 
 
-def make_problem(restore, synth, task, B, H, nfe, seed):
+def make_problem(restore, synth, task, B, H, nfe, seed, blur="gaussian"):
     if task == "deblur":
-        return restore.LoopConfig(task="deblur", iter_num=nfe, lambda_=7.0, zeta=0.3), synth.make_case("deblur", B, H, H, seed=seed, ksize=61)
+        return (restore.LoopConfig(task="deblur", iter_num=nfe, lambda_=7.0, zeta=0.3),
+                synth.make_case("deblur", B, H, H, seed=seed, ksize=61, blur=blur))
     if task == "inpaint":
         return (restore.LoopConfig(task="inpaint", iter_num=nfe, noise_level_img=0.0, lambda_=1.0, zeta=1.0),
                 synth.make_case("inpaint", B, H, H, seed=seed))
@@ -80,21 +97,22 @@ def conv_roofline(eng, B, H, precision, model_name):
     """Instrumented pass: HIP events around every launch of the 3x3 convolution class, 3 forwards of the same batch."""
     x = eng.to_device(np.random.default_rng(0).standard_normal((B, 3, H, H)).astype(np.float32))
     t = np.full(B, 500)
-    o6 = eng.unet_forward(x, t)
+    lab = np.arange(B) % 1000 if model_name == "imagenet512" else None
+    o6 = eng.unet_forward(x, t, lab)
     for _ in range(2):
-        eng.unet_forward(x, t, out=o6)
+        eng.unet_forward(x, t, lab, out=o6)
     eng.sync()
     n_wall = 5
     t0 = time.perf_counter()
     for _ in range(n_wall):
-        eng.unet_forward(x, t, out=o6)
+        eng.unet_forward(x, t, lab, out=o6)
     eng.sync()
     wall_ms = (time.perf_counter() - t0) / n_wall * 1e3           # un-instrumented forward (eager launches)
     eng.prof_enable(True)
     eng.prof_reset()
     n_pass = 3
     for _ in range(n_pass):
-        eng.unet_forward(x, t, out=o6)
+        eng.unet_forward(x, t, lab, out=o6)
     eng.sync()
     prof = eng.prof_read()
     eng.prof_enable(False)
@@ -194,7 +212,7 @@ def main():
     # (RCCL refuses two ranks on one GPU).  Never set by the driver.
     if "DIFFPIR_BENCH_DEVICE" in os.environ:
         local_rank = int(os.environ["DIFFPIR_BENCH_DEVICE"])
-    backend = os.environ.get("DIFFPIR_BENCH_BACKEND", "nccl")
+    backend = os.environ.get("DIFFPIR_BENCH_BACKEND", "rccl")      # rccl = the C ABI's RCCL binding (default); gloo only in the one-GPU tests
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus and world == 1 and args.gpus > 1:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
@@ -202,7 +220,7 @@ def main():
     import diffpir_amd
     from diffpir_amd import restore, synth, script_util, weights, dist as ddist
     torch.cuda.set_device(local_rank)
-    ddist.init(backend)         # "nccl" = RCCL over xGMI; a no-op at WORLD_SIZE == 1
+    ddist.init(backend)         # a no-op at WORLD_SIZE == 1; "rccl": the communicator is created by attach(engine) below
 
     def load(model_name, precision):
         e = diffpir_amd.Engine(local_rank)
@@ -213,21 +231,21 @@ def main():
         return e
 
     eng = load(args.model, args.precision)
-    if os.environ.get("DIFFPIR_COLLECTIVE") == "rccl":      # opt-in: the result all-gather through the C ABI (ncclAllGather via dlopen)
-        ddist.init_rccl(eng, rank, world)
+    ddist.attach(eng)           # ncclCommInitRank on this engine's device (unique id exchanged over MASTER_ADDR:MASTER_PORT)
     B, H = args.batch, args.size
-    cfg, case = make_problem(restore, synth, args.task, B, H, args.nfe, 100 + rank)
+    cfg, case = make_problem(restore, synth, args.task, B, H, args.nfe, 100 + rank, args.blur)
+    labels = (np.arange(B) + rank * B) % 1000 if args.model == "imagenet512" else None
     y = eng.to_device(case["y"])
     k = None if case["k"] is None else eng.to_device(case["k"])
     mask = None if case["mask"] is None else eng.to_device(case["mask"])
     out_f32 = eng.empty((B, 3, H, H))
-    out_u8 = torch.empty((B, H, H, 3), dtype=torch.uint8, device=f"cuda:{local_rank}")     # plumbing for RCCL
+    out_u8 = eng.empty((B, H, H, 3), np.uint8)       # engine-owned send buffer of the one collective
     keep = {}
 
     def one_step():
         # weak scaling: every rank restores its own B images (global indices [rank*B, (rank+1)*B)), then the ONE collective of
         # the path: all-gather of the uint8 results
-        restore.restore_batch(eng, cfg, y, k=k, mask=mask, noise_source="device", seed=1234, image_offset=rank * B,
+        restore.restore_batch(eng, cfg, y, k=k, mask=mask, labels=labels, noise_source="device", seed=1234, image_offset=rank * B,
                               use_graph=not args.no_graph, out_f32=out_f32, out_u8=out_u8, _cache=keep)
         eng.sync()
         ddist.all_gather_results(out_u8, B * world, rank, world, engine=eng)
@@ -246,6 +264,7 @@ def main():
         one_step()
     fence()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device=None if backend == "gloo" else f"cuda:{local_rank}")
+    coll_name = ddist.collective_name()
     value = B * world * args.steps / elapsed
     headline_out = out_f32.numpy()           # before the instrumented passes below reuse the buffer
 
@@ -278,6 +297,36 @@ def main():
                                    "us_per_step": round(us, 2), "algorithmic_bytes": int(fb), "achieved": round(fb / (us * 1e-6) / 1e12, 4),
                                    "frac": round(fb / (us * 1e-6) / 1e12 / PEAK_HBM_TBS, 4), "launches_per_step": 3}
 
+    # ---- the steps either side of the loop (device degradation synthesis, device metrics) and the YAML driver's
+    # end-to-end rate degrade -> 100-NFE loop -> metrics on the headline batch
+    f1 = None
+    if extras and args.task == "deblur":
+        from diffpir_amd import degrade as dgr
+        gt_d = eng.to_device(np.ascontiguousarray((np.clip(case["gt"], 0, 1) * 255).round().astype(np.uint8).transpose(0, 2, 3, 1)))
+        yd, _ops = dgr.degrade(eng, "deblur", gt_d, k=k, noise_level_img=cfg.noise_level_img, seed=5)
+        dgr.metrics(eng, out_f32, gt_d)
+        eng.sync()
+        reps = 5
+        ta = time.perf_counter()
+        for _ in range(reps):
+            dgr.degrade(eng, "deblur", gt_d, k=k, noise_level_img=cfg.noise_level_img, seed=5, out=yd)
+        eng.sync()
+        t_deg = (time.perf_counter() - ta) / reps
+        ta = time.perf_counter()
+        for _ in range(reps):
+            dgr.metrics(eng, out_f32, gt_d)
+        t_met = (time.perf_counter() - ta) / reps
+        ta = time.perf_counter()
+        dgr.degrade(eng, "deblur", gt_d, k=k, noise_level_img=cfg.noise_level_img, seed=5, out=yd)
+        restore.restore_batch(eng, cfg, yd, k=k, noise_source="device", seed=1234, use_graph=not args.no_graph, out_f32=out_f32, out_u8=out_u8, _cache=keep)
+        dgr.metrics(eng, out_f32, gt_d)
+        eng.sync()
+        t_e2e = time.perf_counter() - ta
+        f1 = {"what": "dpir_degrade (61x61 wrap-around blur of the uint8 ground truth in fp64 + AWGN) and dpir_metrics (PSNR / PSNR-Y incl. the "
+                      "D2H of the per-image sums) on the headline batch; end_to_end = degrade -> loop -> metrics, the YAML driver's per-batch work",
+              "degrade_ms": round(t_deg * 1e3, 3), "metrics_ms": round(t_met * 1e3, 3),
+              "end_to_end_images_per_s": round(B / t_e2e, 4), "end_to_end_ms": round(t_e2e * 1e3, 1)}
+
     # ---- secondary measurements in the other arithmetic modes (same inputs, weights, device noise and graph path)
     def other_mode(other):
         eng2 = load(args.model, other)
@@ -286,7 +335,7 @@ def main():
         o2 = eng2.empty((B, 3, H, H)); keep2 = {}
 
         def step2():
-            restore.restore_batch(eng2, cfg, y2, k=k2, mask=m2, noise_source="device", seed=1234, image_offset=0,
+            restore.restore_batch(eng2, cfg, y2, k=k2, mask=m2, labels=labels, noise_source="device", seed=1234, image_offset=0,
                                   use_graph=not args.no_graph, out_f32=o2, _cache=keep2)
             eng2.sync()
         step2()
@@ -317,7 +366,7 @@ def main():
 
     # ---- BASELINE configs[2]: ImageNet-256 topology, x4 SISR, B = 32, 100 NFE
     c3 = None
-    if extras and not args.no_c3 and (args.model, args.task) == ("ffhq", "deblur"):
+    if extras and not args.no_c3 and args.preset == "c2" and (args.model, args.task) == ("ffhq", "deblur"):
         eng.close(); eng_closed = True                       # free the FFHQ workspace before the 40 GB ImageNet one
         e3 = load("imagenet256", args.precision)
         B3 = args.c3_batch
@@ -342,20 +391,24 @@ def main():
     cpu = cpu_baseline_c1(weights, args.cpu_threads) if extras and not args.no_cpu_baseline else None
 
     if rank == 0:
-        cfg_tag = ("configs[1]" if (args.model, args.task, B, args.nfe, H) == ("ffhq", "deblur", 16, 100, 256) else
+        names = {"c2": "configs[1]", "c4": f"configs[3] (batch {B} per GPU; BASELINE quotes 256 images over 8 GPUs)",
+                 "c5": f"configs[4] (batch {B} per GPU; BASELINE quotes 64 images over 8 GPUs)"}
+        cfg_tag = (names[args.preset] if args.exact_preset else
                    "configs[2] topology/task (reduced batch or NFE)" if (args.model, args.task) == ("imagenet256", "sr") else
-                   "BASELINE configs[1] family, non-default flags")
+                   f"BASELINE {names[args.preset].split(' ')[0]} family, non-default flags")
+        psf = {"deblur": "61x61 motion PSF (seeded random walk)" if args.blur == "motion" else "61x61 Gaussian PSF",
+               "sr": "x4, bicubic PSF, FFT prox", "inpaint": "box mask"}[args.task]
         line = {"metric": f"restored images/sec @{args.nfe} NFE, {H}x{H}", "value": round(value, 4), "unit": "images/s",
                 "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
                 "dtype": "f32" if args.precision == "f32" else "f32 (GEMMs as 3 x f16 MFMA on hi/lo-split fp32 operands, fp32 accumulate; exact-fp32-MFMA mode in alt_precision)",
                 "data": "synthetic",
-                "config": {"workload": f"{cfg_tag}: {args.model} topology {H}x{H} {args.task} "
-                                       f"({'61x61 Gaussian PSF' if args.task == 'deblur' else args.task}), {args.nfe} NFE, "
+                "config": {"workload": f"{cfg_tag}: {args.model} topology {H}x{H} {args.task} ({psf}), {args.nfe} NFE, "
                                        f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
-                           "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results"},
-                "roofline": roofline, "roofline_prox": prox, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
+                           "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results",
+                           "collective": coll_name},
+                "roofline": roofline, "roofline_prox": prox, "degrade_metrics": f1, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
         print(json.dumps(line))
     ddist.shutdown()
     if not eng_closed:

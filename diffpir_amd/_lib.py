@@ -86,6 +86,8 @@ SIGNATURES = {
     "dpir_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dpir_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dpir_allgather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
+    "dpir_comm_allreduce_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),
+    "dpir_comm_barrier": (C.c_int, [C.c_void_p]),
     "dpir_comm_destroy": (C.c_int, [C.c_void_p]),
     "dpir_degrade": (C.c_int, [C.c_void_p, C.POINTER(DegradeDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "dpir_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
@@ -103,6 +105,31 @@ _lib = None
 
 class EngineLibraryError(RuntimeError):
     pass
+
+
+DEBUG_LIB_PATH = os.path.join(_HERE, "csrc", "libdiffpir_dbg.so")
+_dbg = None
+
+
+def load_debug():
+    """Development probes (include/diffpir_debug.h) live in their own library; tests/ and tools/ only -- the product path never
+    loads it.  Binds the probes' signatures."""
+    global _dbg
+    if _dbg is not None:
+        return _dbg
+    load()
+    if not os.path.exists(DEBUG_LIB_PATH):
+        raise EngineLibraryError(f"{DEBUG_LIB_PATH} not found: `make -C diffpir_amd/csrc` builds it next to the product library")
+    d = C.CDLL(DEBUG_LIB_PATH)
+    d.dpir_debug_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_double)]
+    d.dpir_debug_victim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_ulonglong)]
+    d.dpir_debug_victim_alu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    for fn in (d.dpir_debug_victim_fft_pk, d.dpir_debug_victim_fft_nopk):
+        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    for n in ("dpir_debug_conv_bench", "dpir_debug_victim", "dpir_debug_victim_alu", "dpir_debug_victim_fft_pk", "dpir_debug_victim_fft_nopk"):
+        getattr(d, n).restype = C.c_int
+    _dbg = d
+    return d
 
 
 def load():

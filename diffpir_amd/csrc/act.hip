@@ -171,28 +171,33 @@ __device__ __forceinline__ void store_halves(_Float16* dst, const _Float16* v) {
     else dst[0] = v[0];
 }
 
-template <int CQ>
-__global__ __launch_bounds__(256) void gn_act_small_kernel(GnActK p) {
-    const int tid = threadIdx.x;
+// KMAX: compile-time bound of the split-K factor (0: no pending convolution).  All slab loads of an element are issued before the
+// first add -- a run-time loop of load/add pairs is a chain of KMAX dependent HBM latencies.
+template <int CQ, int KMAX>
+__global__ __launch_bounds__(1024) void gn_act_small_kernel(GnActK p) {
+    const int tid = threadIdx.x, NT = blockDim.x;      // 256 ... 1024 threads: enough to give every thread <= ~4 elements
     const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
     const int C = p.ca + p.cb, cg = C >> 5, c0 = g * cg;
     const int HWs = p.Hs * p.Ws, n4 = HWs >> 2;
     // ---- pass 1
     double S = 0.0, SS = 0.0;
     const size_t slab = (size_t)gridDim.x / 32 * p.ca * HWs;          // one split-K slab = the whole [B, ca, Hs, Ws] tensor
-    for (int e = tid; e < cg * n4; e += 256) {
+    for (int e = tid; e < cg * n4; e += NT) {
         const int k = e / n4, i4 = e - k * n4;
         const int c = c0 + k;
         float4 v;
         if (c < p.ca) {
             const size_t plane = (size_t)n * p.ca + c;
             const size_t o = plane * HWs + (size_t)i4 * 4;
-            if (p.partial) {
+            if (KMAX > 0) {
+                float4 t[KMAX > 0 ? KMAX : 1];
+#pragma unroll
+                for (int q = 0; q < KMAX; ++q)          // slabs beyond ksplit: the last one again (cache hit), not added
+                    t[q] = *reinterpret_cast<const float4*>(p.partial + (size_t)(q < p.ksplit ? q : p.ksplit - 1) * slab + o);
                 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                for (int q = 0; q < p.ksplit; ++q) {
-                    const float4 t = *reinterpret_cast<const float4*>(p.partial + (size_t)q * slab + o);
-                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
-                }
+#pragma unroll
+                for (int q = 0; q < KMAX; ++q)
+                    if (q < p.ksplit) { v.x += t[q].x; v.y += t[q].y; v.z += t[q].z; v.w += t[q].w; }
                 const float bv = p.bias[c];
                 v.x += bv; v.y += bv; v.z += bv; v.w += bv;
                 if (p.res) {
@@ -226,7 +231,7 @@ __global__ __launch_bounds__(256) void gn_act_small_kernel(GnActK p) {
         S += ((double)v.x + (double)v.y) + ((double)v.z + (double)v.w);
         SS += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
     }
-    __shared__ double red[2][4];
+    __shared__ double red[2][16];
     __shared__ float sh_mean;
     __shared__ float sh_a[64], sh_b[64];
 #pragma unroll
@@ -235,8 +240,8 @@ __global__ __launch_bounds__(256) void gn_act_small_kernel(GnActK p) {
     __threadfence_block();
     __syncthreads();
     if (tid < cg) {
-        const double s = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
-        const double ss = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        double s = 0.0, ss = 0.0;
+        for (int w = 0; w < (NT >> 6); ++w) { s += red[0][w]; ss += red[1][w]; }       // fixed order
         const double cnt = (double)cg * HWs;
         const double mean = s / cnt;
         double var = ss / cnt - mean * mean;
@@ -260,9 +265,9 @@ __global__ __launch_bounds__(256) void gn_act_small_kernel(GnActK p) {
     const float mean = sh_mean;
     const int HWo = p.Ho * p.Wo;
     const int nq = cg / CQ;
-    const float* ta = p.partial ? p.pend_out : p.a;
+    const float* ta = KMAX > 0 ? p.pend_out : p.a;
     bool bad = false;
-    for (int q = tid; q < nq * HWo; q += 256) {
+    for (int q = tid; q < nq * HWo; q += NT) {
         const int cq = q / HWo, pix = q - cq * HWo;
         const int y = pix / p.Wo, x = pix - y * p.Wo;
         const int so = p.mode == 0 ? pix : (p.mode == 1 ? (y >> 1) * p.Ws + (x >> 1) : (2 * y) * p.Ws + 2 * x);
@@ -324,9 +329,21 @@ Status launch_gn_act_small(hipStream_t s, const GnActArgs& a) {
     k.range_ctr = a.range_ctr;
     const int cg = C / 32;
     const dim3 grid((unsigned)(a.B * 32));
-    if (cg % 4 == 0) hipLaunchKernelGGL(gn_act_small_kernel<4>, grid, dim3(256), 0, s, k);
-    else if (cg % 2 == 0) hipLaunchKernelGGL(gn_act_small_kernel<2>, grid, dim3(256), 0, s, k);
-    else hipLaunchKernelGGL(gn_act_small_kernel<1>, grid, dim3(256), 0, s, k);
+    if (k.partial && (k.ksplit < 2 || k.ksplit > 16)) return invalid("gn_act_small: split-K factor out of range");
+    const int kmax = !k.partial ? 0 : (k.ksplit <= 4 ? 4 : (k.ksplit <= 8 ? 8 : 16));
+    const int work = (C / 32) * ((a.Hs * a.Ws) >> 2);                      // float4 elements of pass 1 per workgroup
+    const unsigned nt = work >= 2048 ? 1024u : (work >= 1024 ? 512u : 256u);
+#define DPIR_GNACT(CQ)                                                                                                  \
+    do {                                                                                                                \
+        if (kmax == 0) hipLaunchKernelGGL((gn_act_small_kernel<CQ, 0>), grid, dim3(nt), 0, s, k);                       \
+        else if (kmax == 4) hipLaunchKernelGGL((gn_act_small_kernel<CQ, 4>), grid, dim3(nt), 0, s, k);                  \
+        else if (kmax == 8) hipLaunchKernelGGL((gn_act_small_kernel<CQ, 8>), grid, dim3(nt), 0, s, k);                  \
+        else hipLaunchKernelGGL((gn_act_small_kernel<CQ, 16>), grid, dim3(nt), 0, s, k);                                \
+    } while (0)
+    if (cg % 4 == 0) DPIR_GNACT(4);
+    else if (cg % 2 == 0) DPIR_GNACT(2);
+    else DPIR_GNACT(1);
+#undef DPIR_GNACT
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

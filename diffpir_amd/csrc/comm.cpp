@@ -5,6 +5,7 @@
 #include "engine.h"
 #include <dlfcn.h>
 #include <string.h>
+#include <mutex>
 
 namespace {
 typedef struct { char internal[128]; } UniqueId;        // ncclUniqueId (rccl.h:43, NCCL_UNIQUE_ID_BYTES 128)
@@ -14,10 +15,13 @@ struct Rccl {
     int (*GetUniqueId)(UniqueId*) = nullptr;
     int (*CommInitRank)(Comm*, int, UniqueId, int) = nullptr;
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
+    std::mutex mu;
     bool load() {
+        std::lock_guard<std::mutex> lk(mu);       // engines are driven from several host threads
         if (lib) return true;
         for (const char* name : {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
@@ -27,15 +31,18 @@ struct Rccl {
         GetUniqueId = reinterpret_cast<decltype(GetUniqueId)>(dlsym(lib, "ncclGetUniqueId"));
         CommInitRank = reinterpret_cast<decltype(CommInitRank)>(dlsym(lib, "ncclCommInitRank"));
         AllGather = reinterpret_cast<decltype(AllGather)>(dlsym(lib, "ncclAllGather"));
+        AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
-        if (!GetUniqueId || !CommInitRank || !AllGather || !CommDestroy) { err = "librccl.so lacks an expected symbol"; lib = nullptr; return false; }
+        if (!GetUniqueId || !CommInitRank || !AllGather || !AllReduce || !CommDestroy) { err = "librccl.so lacks an expected symbol"; lib = nullptr; return false; }
         return true;
     }
     std::string what(int rc) { return GetErrorString ? std::string(GetErrorString(rc)) : std::to_string(rc); }
 };
 Rccl g_rccl;
 constexpr int kNcclUint8 = 1;      // ncclUint8 (rccl.h ncclDataType_t: ncclInt8 = 0, ncclUint8 = 1)
+constexpr int kNcclFloat64 = 8;    // ncclFloat64 / ncclDouble
+constexpr int kNcclMax = 2;        // ncclRedOp_t: ncclSum 0, ncclProd 1, ncclMax 2, ncclMin 3
 
 int fail(dpir_engine* e, int code, const std::string& msg) {
     if (e) e->last_error = msg;
@@ -74,6 +81,28 @@ int dpir_allgather_results(dpir_engine* e, const void* send_dev, void* recv_dev,
     int rc = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, kNcclUint8, e->comm, e->stream);      // stream-ordered behind the loop
     if (rc != 0) return fail(e, DPIR_ERR_HIP, "ncclAllGather: " + g_rccl.what(rc));
     return DPIR_OK;
+}
+
+// MAX all-reduce of one host double over the communicator (the bench's elapsed time; a barrier when the value is ignored):
+// staged through an engine-owned 8-byte device word on the engine stream, synchronous.
+int dpir_comm_allreduce_max(dpir_engine* e, double* value_inout) {
+    if (!e || !value_inout) return fail(e, DPIR_ERR_INVALID, "dpir_comm_allreduce_max: null argument");
+    if (!e->comm) return fail(e, DPIR_ERR_STATE, "dpir_comm_allreduce_max: dpir_comm_init has not been called");
+    (void)hipSetDevice(e->device);
+    double* w = nullptr;
+    dpir::Status st = e->ws.getT("comm#word", (size_t)2, &w);
+    if (!st.ok()) return fail(e, st.code, st.msg);
+    if (hipMemcpyAsync(w, value_inout, sizeof(double), hipMemcpyHostToDevice, e->stream) != hipSuccess) return fail(e, DPIR_ERR_HIP, "comm word upload failed");
+    int rc = g_rccl.AllReduce(w, w + 1, 1, kNcclFloat64, kNcclMax, e->comm, e->stream);
+    if (rc != 0) return fail(e, DPIR_ERR_HIP, "ncclAllReduce: " + g_rccl.what(rc));
+    if (hipMemcpyAsync(value_inout, w + 1, sizeof(double), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
+        hipStreamSynchronize(e->stream) != hipSuccess) return fail(e, DPIR_ERR_HIP, "comm word download failed");
+    return DPIR_OK;
+}
+
+int dpir_comm_barrier(dpir_engine* e) {
+    double v = 0.0;
+    return dpir_comm_allreduce_max(e, &v);
 }
 
 int dpir_comm_destroy(dpir_engine* e) {

@@ -166,6 +166,9 @@ struct Conv5Args {
     int B = 0, Cout = 0, H = 0, W = 0;
     unsigned long long* range_ctr = nullptr;   // f16 operand range guard (act.hip range_report)
     bool x1 = false;                           // single-product mode (f16x1)
+    // optional second product: the split operand planes of the following 3x3 convolution, silu(GroupNorm(src)) per emit_prm,
+    // blocked [B][2*ceil(C/16)][HW][8] f16 (act.hip's layout); requires prm == null (the 1x1 itself multiplies the raw input)
+    const float4* emit_prm = nullptr; void* emit_hi = nullptr; void* emit_lo = nullptr;
 };
 bool conv5_supported(int B, int Cout, int H, int W);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);

@@ -23,20 +23,28 @@ struct Conv5K {
     const float* zeros;
     float out_scale;
     unsigned long long* range_ctr;
+    // EMIT: the kernel also produces the split operand planes of the ResBlock's first 3x3 convolution from the SAME input rows
+    // (GroupNorm affine + SiLU per eprm, f16 hi/lo, blocked [n][C8][HW][8] as act.hip writes them): the concat input of an
+    // output-path ResBlock is read from HBM once for the 1x1 skip projection and for in_layers (unet.py:236-256).
+    const float4* eprm; _Float16* ehi; _Float16* elo; int eC8;
 };
 
 #define GLDS5(src, dst) \
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src), \
                                      (__attribute__((address_space(3))) void*)(dst), 16, 0, 0)
 
-template <bool HAS_PRM, bool X1>
+template <bool HAS_PRM, bool X1, bool EMIT>
 __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
+    static_assert(!(HAS_PRM && EMIT), "the emitting variant multiplies the raw input");
     constexpr int WCO = 4, WPX = 2;
     constexpr int XBYTES = 16 * 1024;        // [16 ch][256 px] fp32
     constexpr int WBYTES = 8 * 1024;         // [hi|lo][k-half][128 co][8] f16
     __shared__ __attribute__((aligned(16))) char smem5[2 * XBYTES + 2 * WBYTES];
     char* lds_x = smem5;
     char* lds_w = smem5 + 2 * XBYTES;
+    // EMIT: the GroupNorm table of the tile's image, staged once (a 256-pixel tile lies inside one image: HW % 256 == 0); read
+    // back as half-wave broadcasts -- per-lane global loads of it (16 per chunk) made the kernel request-bound
+    __shared__ float4 eprm_sh[EMIT ? 1024 : 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,11 +84,14 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
 
     // ---- this lane's B-fragment pixels
     int pxl[WPX]; int pn[WPX];
+    size_t eoff[WPX]; bool eok[WPX];       // EMIT: entry index of (image, k-group 0, pixel) in the planes
 #pragma unroll
     for (int j = 0; j < WPX; ++j) {
         pxl[j] = wave * 64 + j * 32 + l31;
         long long g = px0 + pxl[j];
         pn[j] = g < p.total_px ? (int)(g / HW) : 0;
+        eok[j] = EMIT && co_blk == 0 && g < p.total_px;
+        eoff[j] = EMIT ? ((size_t)pn[j] * p.eC8 + half) * HW + (size_t)(g - (long long)pn[j] * HW) : 0;
     }
 
     floatx16 acc[WCO][WPX];
@@ -92,6 +103,10 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     bool bad = false;
+    if (EMIT) {
+        const int n_tile = (int)(px0 / HW);
+        for (int c = tid; c < C; c += 256) eprm_sh[c] = p.eprm[(size_t)n_tile * C + c];
+    }
     issue_dma(0, 0);
     for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
         const int cur = chunk & 1;
@@ -117,6 +132,29 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
                         if (m.w != 0.f) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
                         v[jj] = t;
                     }
+                }
+            }
+            if (EMIT) {
+                if (eok[j]) {
+                    half8 eh, el;
+#pragma unroll
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int c = chunk * 16 + 8 * half + jj;
+                        float t = 0.f;
+                        if (c < C) {
+                            const float4 m = eprm_sh[c];
+                            t = (v[jj] - m.x) * m.y + m.z;
+                            if (m.w != 0.f) t = t * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(t * -1.4426950408889634f));
+                        }
+                        bad |= !(fabsf(t) <= 65000.f);
+                        t = fminf(fmaxf(t, -65000.f), 65000.f);
+                        const _Float16 hh = (_Float16)t;
+                        eh[jj] = hh;
+                        el[jj] = (_Float16)(t - (float)hh);
+                    }
+                    const size_t eo = (eoff[j] + (size_t)chunk * 2 * HW) * 8;
+                    *reinterpret_cast<half8*>(p.ehi + eo) = eh;
+                    if (!X1) *reinterpret_cast<half8*>(p.elo + eo) = el;
                 }
             }
 #pragma unroll
@@ -216,12 +254,19 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a) {
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv5: cannot allocate the zero page"};
     k.out_scale = 1.0f / a.w16_scale;
     k.range_ctr = a.range_ctr;
+    k.eprm = a.emit_prm; k.ehi = reinterpret_cast<_Float16*>(a.emit_hi); k.elo = reinterpret_cast<_Float16*>(a.emit_lo);
+    k.eC8 = 2 * k.n_chunks;
     const unsigned blocks = (unsigned)(((k.total_px + 255) / 256) * k.n_co_blocks);
-    if (a.x1) {
-        if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, true>), dim3(blocks), dim3(256), 0, s, k);
-        else hipLaunchKernelGGL((conv5_mfma_kernel<false, true>), dim3(blocks), dim3(256), 0, s, k);
-    } else if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, false>), dim3(blocks), dim3(256), 0, s, k);
-    else hipLaunchKernelGGL((conv5_mfma_kernel<false, false>), dim3(blocks), dim3(256), 0, s, k);
+    if (a.emit_hi) {
+        if (a.prm || !a.emit_prm || (!a.x1 && !a.emit_lo)) return invalid("conv5: the plane-emitting variant takes the raw input and a GroupNorm table for the planes");
+        if ((a.H * a.W) % 256 || a.src.ca + a.src.cb > 1024) return invalid("conv5: the plane-emitting variant needs H*W % 256 == 0 and at most 1024 input channels");
+        if (a.x1) hipLaunchKernelGGL((conv5_mfma_kernel<false, true, true>), dim3(blocks), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((conv5_mfma_kernel<false, false, true>), dim3(blocks), dim3(256), 0, s, k);
+    } else if (a.x1) {
+        if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, true, false>), dim3(blocks), dim3(256), 0, s, k);
+        else hipLaunchKernelGGL((conv5_mfma_kernel<false, true, false>), dim3(blocks), dim3(256), 0, s, k);
+    } else if (a.prm) hipLaunchKernelGGL((conv5_mfma_kernel<true, false, false>), dim3(blocks), dim3(256), 0, s, k);
+    else hipLaunchKernelGGL((conv5_mfma_kernel<false, false, false>), dim3(blocks), dim3(256), 0, s, k);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

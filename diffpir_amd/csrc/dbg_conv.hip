@@ -1,0 +1,95 @@
+// Development-only: one convolution shape timed in isolation (include/diffpir_debug.h).  Part of libdiffpir_dbg.so, which links
+// against the product library and uses its internal launchers; nothing here is on the product path.
+#include "engine.h"
+#include "../../include/diffpir_debug.h"
+#include <vector>
+using namespace dpir;
+static int fail(dpir_engine* e, const Status& s) {
+    if (e) e->last_error = s.msg;
+    return s.code;
+}
+#define API_TRY(e, expr)                          \
+    do {                                          \
+        Status _s = (expr);                       \
+        if (!_s.ok()) return fail((e), _s);       \
+    } while (0)
+#define API_HIP(e, expr)                                                                  \
+    do {                                                                                  \
+        hipError_t _h = (expr);                                                           \
+        if (_h != hipSuccess)                                                             \
+            return fail((e), Status{DPIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_h)}); \
+    } while (0)
+
+extern "C" {
+// Times one convolution shape in isolation (synthetic operands already on the device).  mode bits: 0 = exact-fp32 kernels,
+// 1 = f16x3 (conv6 for 3x3 incl. its act_split pre-pass, conv5 for 1x1), 2 = f16x3 without the pre-pass (planes prepared once).
+// Not part of the product path; used by tools/ only.
+int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int ks, int mode, int with_prm,
+                          int dbg, int iters, double* ms_out) {
+    if (!e || !ms_out || iters <= 0) return DPIR_ERR_INVALID;
+    (void)hipSetDevice(e->device);
+    int taps = ks * ks, coutp = round_up(Cout, 64), cinp = round_up(Cin, 16);
+    float *x = nullptr, *w = nullptr, *bias = nullptr, *out = nullptr, *partial = nullptr; float4* prm = nullptr;
+    API_TRY(e, e->ws.getT("dbg#x", (size_t)B * Cin * H * W, &x));
+    API_TRY(e, e->ws.getT("dbg#w", (size_t)cinp * taps * coutp, &w));
+    API_TRY(e, e->ws.getT("dbg#b", (size_t)coutp, &bias));
+    API_TRY(e, e->ws.getT("dbg#o", (size_t)B * Cout * H * W, &out));
+    API_TRY(e, e->ws.getT("dbg#prm", (size_t)B * Cin, &prm));
+    API_TRY(e, e->ws.getT("conv#partial", (size_t)16 * 1024 * 1024, &partial));
+    API_TRY(e, launch_randn(e->stream, x, 1, 1, 0, 1, (size_t)B * Cin * H * W));
+    API_TRY(e, launch_randn(e->stream, w, 2, 1, 0, 1, (size_t)cinp * taps * coutp));
+    API_TRY(e, launch_randn(e->stream, bias, 3, 1, 0, 1, (size_t)coutp));
+    API_TRY(e, launch_randn(e->stream, reinterpret_cast<float*>(prm), 4, 1, 0, 1, (size_t)B * Cin * 4));
+    ConvArgs a;
+    a.src.a = x; a.src.ca = Cin; a.src.Hs = H; a.src.Ws = W; a.src.mode = 0; a.src.prm = with_prm ? prm : nullptr;
+    a.w = w; a.bias = bias; a.out = out; a.B = B; a.Cin = Cin; a.Cout = Cout; a.CoutP = coutp; a.H = H; a.W = W; a.ks = ks;
+    a.partial = partial; a.partial_capacity = (size_t)16 * 1024 * 1024;
+    const void* w16 = nullptr; float w16_scale = 1.f;
+    if (dbg != 0) {   // operand-split f16 path with synthetic split weights
+        std::vector<float> hw((size_t)Cout * Cin * taps);
+        for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
+        std::vector<uint16_t> w16v;
+        w16_scale = ks == 1 ? pack_weights_f16x3_1x1(hw.data(), Cout, Cin, w16v) : pack_weights_conv6(hw.data(), Cout, Cin, w16v);
+        void* wp = nullptr;
+        API_TRY(e, e->ws.get("dbg#w16", w16v.size() * 2, &wp));
+        API_HIP(e, hipMemcpy(wp, w16v.data(), w16v.size() * 2, hipMemcpyHostToDevice));
+        w16 = wp;
+    }
+    Conv5Args a5;
+    Conv6Args a6;
+    const bool use5 = dbg != 0 && ks == 1, use6 = dbg != 0 && ks == 3;
+    if (use5) {
+        a5.src = CatSrc{x, Cin, nullptr, 0}; a5.prm = a.src.prm; a5.w16 = w16; a5.w16_scale = w16_scale; a5.bias = bias; a5.out = out;
+        a5.B = B; a5.Cout = Cout; a5.H = H; a5.W = W;
+    }
+    if (use6) {
+        int C8 = 2 * ((Cin + 15) / 16);
+        size_t plane = (size_t)B * C8 * H * W * 16;
+        char* s16 = nullptr;
+        API_TRY(e, e->ws.getT("dbg#s16", 2 * plane, &s16));
+        API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, 0, B, H, W, s16, s16 + plane));
+        a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = w16; a6.w16_scale = w16_scale; a6.bias = bias; a6.out = out;
+        a6.B = B; a6.Cin = Cin; a6.Cout = Cout; a6.H = H; a6.W = W; a6.partial = partial; a6.partial_capacity = a.partial_capacity;
+    }
+    auto run_once = [&]() -> Status {
+        if (use5) return launch_conv5(e->stream, a5);
+        if (use6) {
+            if (dbg == 1) DPIR_TRY(launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, 0, B, H, W, const_cast<void*>(a6.xhi), const_cast<void*>(a6.xlo)));
+            return launch_conv6(e->stream, a6);
+        }
+        return launch_conv(e->stream, a);
+    };
+    API_TRY(e, run_once());
+    hipEvent_t e0, e1;
+    API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1));
+    API_HIP(e, hipEventRecord(e0, e->stream));
+    for (int i = 0; i < iters; ++i) API_TRY(e, run_once());
+    API_HIP(e, hipEventRecord(e1, e->stream));
+    API_HIP(e, hipEventSynchronize(e1));
+    float ms = 0; API_HIP(e, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_out = ms / iters;
+    return DPIR_OK;
+}
+
+}  // extern "C"

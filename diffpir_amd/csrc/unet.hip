@@ -284,6 +284,7 @@ struct Fwd {
     // reuses the slab buffer.
     PendingConv pending;
     bool fuse_small;
+    bool emit_skip;       // conv5 emits conv1's operand planes in ResBlocks with a 1x1 skip projection
 
     Status resolve() {
         if (!pending.partial) return Status{};
@@ -436,10 +437,43 @@ struct Fwd {
         size_t on = (size_t)B * r.cout * Ho * Wo;
         float* h1 = nullptr;
         DPIR_TRY(ws.getT(r.name + "#h1", on, &h1));
-        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo));
-        tap(r.name + "#h1", h1, on);
         Act h1a; h1a.a = h1; h1a.ca = r.cout; h1a.H = Ho; h1a.W = Wo;
         const float* res = nullptr; int res_mode = 0;
+        // ResBlock with a 1x1 skip projection at a resolution the fused low-resolution prologue does not take: ONE pass over the
+        // (concat) input feeds both the skip projection and in_layers -- conv5 emits conv1's split operand planes
+        const int Cin = in.C();
+        const size_t eplane = (size_t)B * (2 * ((Cin + 15) / 16)) * Ho * Wo * 16;
+        if (emit_skip && r.has_skip && r.mode == 0 && r.conv1.w16 && r.skip.w16 && conv6_supported(Ho, Wo) && conv5_supported(B, r.cout, Ho, Wo) &&
+            Cin % 16 == 0 && Cin <= 1024 && (Ho * Wo) % 256 == 0 && eplane < ((size_t)1 << 32) && !(fuse_small && gn_act_small_supported(Cin, in.H, in.W, 0))) {
+            const bool x1 = e->precision == 2;
+            float4* prm1 = nullptr;
+            DPIR_TRY(resolve());
+            DPIR_TRY(gn(r.gn1, in, r.name + "#gn1", -1, true, &prm1));
+            char* s16 = nullptr;
+            DPIR_TRY(ws.getT("act#s16", 2 * eplane, &s16));
+            float* sk = nullptr;
+            DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
+            Conv5Args a5;
+            a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = nullptr; a5.w16 = r.skip.w16; a5.w16_scale = r.skip.w16_scale;
+            a5.bias = r.skip.bias; a5.out = sk; a5.res = nullptr; a5.B = B; a5.Cout = r.cout; a5.H = Ho; a5.W = Wo;
+            a5.range_ctr = e->range_ctr; a5.x1 = x1;
+            a5.emit_prm = prm1; a5.emit_hi = s16; a5.emit_lo = x1 ? nullptr : s16 + eplane;
+            fused.erase(sk);
+            {
+                ProfScope ps(&e->prof, PC_CONV1);
+                DPIR_TRY(launch_conv5(s, a5));
+            }
+            DPIR_TRY(conv6_on_planes(r.conv1, s16, eplane, nullptr, 0, h1, Ho, Wo));
+            tap(r.name + "#h1", h1, on);
+            float* o = nullptr;
+            DPIR_TRY(ws.getT(r.name + "#out", on, &o));
+            DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, sk, 0, o, Ho, Wo));
+            tap(r.name, o, on);
+            out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
+            return Status{};
+        }
+        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo));
+        tap(r.name + "#h1", h1, on);
         if (r.has_skip) {
             float* sk = nullptr;
             DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
@@ -541,7 +575,9 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     Fwd f{e, s, ws, B, hoisted ? film_table : film, net.film_rows, hoisted ? 0 : net.film_rows, hoisted ? film_step : nullptr, partial, partial_cap};
     {
         static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
+        static const bool emit_env = !(getenv("DPIR_EMIT_SKIP") && atoi(getenv("DPIR_EMIT_SKIP")) == 0);
         f.fuse_small = fuse_env;
+        f.emit_skip = emit_env;
     }
     if (e->collect_taps) e->taps.clear();
 

@@ -1,14 +1,25 @@
 """Image sharding across the GPUs of a node (one process per GPU) and the single result collective.
 
 The restoration path has no cross-image coupling: a batch is block-partitioned over ranks, every
-rank runs its own loop, and the only exchange is one all-gather of the results (RCCL over xGMI with backend
-"nccl"; "gloo" on CPU for tests).  Device noise is keyed by the GLOBAL image index (`image_offset`), so outputs
-do not depend on the number of ranks.
+rank runs its own loop, and the only exchange is one all-gather of the results.  Device noise is keyed by the GLOBAL
+image index (`image_offset`), so outputs do not depend on the number of ranks.
+
+Collective back-ends (`init(collective)`, overridden by DIFFPIR_COLLECTIVE):
+  * "rccl"  (default, the product path): RCCL over xGMI bound through the C ABI (`dpir_comm_init`, `dpir_allgather_results`,
+    `dpir_comm_barrier`, `dpir_comm_allreduce_max`; csrc/comm.cpp dlopens librccl).  Buffers are engine-owned DeviceArrays, the
+    collective runs on the engine stream, and the rendezvous is one TCP exchange of the 128-byte ncclUniqueId on
+    MASTER_ADDR:MASTER_PORT (the variables the one-process-per-GPU launcher exports).  No torch in the data path.
+  * "nccl" / "gloo": torch.distributed -- kept as the rendezvous fallback and for the tests that run several ranks on ONE GPU or
+    on CPU (RCCL refuses two ranks on one device).
 """
 from __future__ import annotations
 
 import os
 from typing import Tuple
+
+import numpy as np
+
+_state = {"mode": "single", "engine": None, "rank": 0, "world": 1}
 
 
 def env_rank_world() -> Tuple[int, int, int]:
@@ -22,49 +33,95 @@ def shard_range(n_images: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-def init(backend: str = "nccl"):
-    """One process per GPU (launched by torch.distributed.run): joins the process group when WORLD_SIZE > 1.
-    backend "nccl" is RCCL over xGMI on ROCm; "gloo" (host staging) is what the single-GPU / CPU tests use."""
-    import torch.distributed as dist
+def init(collective: str = "rccl"):
+    """One process per GPU (launched by torch.distributed.run or any launcher that exports RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT).  Returns (rank, local_rank, world).  With the default "rccl" collective the communicator is
+    created by `attach(engine)` once the rank's engine exists; "nccl" / "gloo" join a torch.distributed process group here."""
     rank, local_rank, world = env_rank_world()
-    # DIFFPIR_FORCE_DIST=1 joins the group at WORLD_SIZE == 1 too, so that the RCCL code path (init, barrier, all_gather,
-    # all_reduce) can be exercised on a single-GPU box exactly as the multi-GPU launch runs it (tests/test_gpu_dist.py)
-    if (world > 1 or os.environ.get("DIFFPIR_FORCE_DIST") == "1") and not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend, rank=rank, world_size=world)
+    collective = os.environ.get("DIFFPIR_COLLECTIVE", collective)
+    if collective == "torch":
+        collective = "nccl"
+    # DIFFPIR_FORCE_DIST=1 runs the collective code path at WORLD_SIZE == 1 too, exactly as the multi-GPU launch runs it
+    active = world > 1 or os.environ.get("DIFFPIR_FORCE_DIST") == "1"
+    _state.update(mode="single", engine=None, rank=rank, world=world)
+    if not active:
+        return rank, local_rank, world
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if collective == "rccl":
+        _state["mode"] = "rccl-pending"
+    elif collective in ("nccl", "gloo"):
+        import torch.distributed as dist
+        if not dist.is_initialized():
+            dist.init_process_group(collective, rank=rank, world_size=world)
+        _state["mode"] = "torch"
+    else:
+        raise ValueError(f"unknown collective {collective!r} (rccl | nccl | gloo)")
     return rank, local_rank, world
 
 
+def attach(engine):
+    """Bind this rank's engine to the group: creates the RCCL communicator on the engine's device (rccl mode)."""
+    if _state["mode"] == "rccl-pending":
+        init_rccl(engine, _state["rank"], _state["world"])
+        _state.update(mode="rccl", engine=engine)
+    elif _state["mode"] == "torch":
+        _state["engine"] = engine
+
+
+def collective_name() -> str:
+    if _state["mode"] == "torch":
+        import torch.distributed as dist
+        return f"torch.distributed/{dist.get_backend()}"
+    return {"rccl": "RCCL via the C ABI (dpir_allgather_results)", "rccl-pending": "RCCL via the C ABI (not attached)"}.get(_state["mode"], "none")
+
+
 def barrier():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
+    if _state["mode"] == "rccl":
+        e = _state["engine"]
+        e._check(e.lib.dpir_comm_barrier(e.h))
+    elif _state["mode"] == "torch":
+        import torch.distributed as dist
         dist.barrier()
 
 
 def max_over_ranks(value: float, device=None) -> float:
     """MAX all-reduce of one scalar (the bench's elapsed time)."""
-    import torch
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()):
-        return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    return float(t.item())
+    if _state["mode"] == "rccl":
+        import ctypes as C
+        e = _state["engine"]
+        v = C.c_double(float(value))
+        e._check(e.lib.dpir_comm_allreduce_max(e.h, C.byref(v)))
+        return float(v.value)
+    if _state["mode"] == "torch":
+        import torch
+        import torch.distributed as dist
+        if dist.get_backend() == "gloo":
+            device = None
+        t = torch.tensor([value], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+    return value
 
 
 def shutdown():
-    import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized():
-        dist.barrier()
-        dist.destroy_process_group()
+    if _state["mode"] == "rccl":
+        barrier()
+        e = _state["engine"]
+        e.lib.dpir_comm_destroy(e.h)
+        e.rccl = False
+    elif _state["mode"] == "torch":
+        import torch.distributed as dist
+        if dist.is_initialized():
+            dist.barrier()
+            dist.destroy_process_group()
+    _state.update(mode="single", engine=None)
 
 
 def init_rccl(engine, rank: int, world: int, port: int = None):
-    """Bind the result collective straight to RCCL through the C ABI (dpir_comm_init / dpir_allgather_results): rank 0 creates
-    the 128-byte ncclUniqueId and ships it to the other ranks over a TCP socket on MASTER_ADDR (stdlib; rendezvous plumbing
-    only), then every rank joins the communicator on its engine's device.  Selected with DIFFPIR_COLLECTIVE=rccl."""
+    """Rank 0 creates the 128-byte ncclUniqueId and ships it to the other ranks over a TCP socket on MASTER_ADDR (stdlib;
+    rendezvous plumbing only), then every rank joins the communicator on its engine's device (dpir_comm_init)."""
     import ctypes as C
     import socket
     import time
@@ -104,27 +161,66 @@ def init_rccl(engine, rank: int, world: int, port: int = None):
     engine.rccl = True
 
 
+def _gather_rccl(engine, local, n_images: int, rank: int, world: int):
+    """ncclAllGather through the C ABI on the engine stream.  `local`: DeviceArray [n_local, ...] (any dtype, moved as bytes) or a
+    host numpy array (small per-image metrics: staged through engine-owned device words).  Returns the same kind, [n_images, ...]."""
+    from .engine import DeviceArray
+    host = not isinstance(local, DeviceArray)
+    if host:
+        a = np.ascontiguousarray(local)
+        dev = engine.empty(a.shape, a.dtype)
+        if a.size:
+            dev.copy_from(a)
+        local = dev
+    sizes = [shard_range(n_images, r, world) for r in range(world)]
+    mx = max(hi - lo for lo, hi in sizes)
+    item = tuple(local.shape[1:])
+    row_bytes = int(np.prod(item, dtype=np.int64)) * local.dtype.itemsize
+    send = local
+    if local.shape[0] < mx:                    # ragged shards: pad to the largest shard for the collective
+        send = engine.empty((mx,) + item, local.dtype)
+        if local.shape[0]:
+            engine._check(engine.lib.dpir_d2d(engine.h, send.ptr, local.ptr, local.shape[0] * row_bytes))
+    recv = engine.empty((world * mx,) + item, local.dtype)
+    engine._check(engine.lib.dpir_allgather_results(engine.h, send.ptr, recv.ptr, mx * row_bytes))
+    if all(hi - lo == mx for lo, hi in sizes):
+        out = recv                               # recv is already [n_images, ...]
+    else:
+        out = engine.empty((n_images,) + item, local.dtype)
+        for r, (lo, hi) in enumerate(sizes):
+            if hi > lo:
+                engine._check(engine.lib.dpir_d2d(engine.h, out.ptr + lo * row_bytes, recv.ptr + r * mx * row_bytes, (hi - lo) * row_bytes))
+    engine.sync()
+    return out.numpy() if host else out
+
+
 def all_gather_results(local, n_images: int, rank: int, world: int, engine=None):
-    """local: torch tensor [n_local, ...] (uint8 NHWC results).  Returns [n_images, ...] on every rank.
-    Shards may differ by one image, so each is padded to the largest shard for the collective.
-    engine with an RCCL communicator (init_rccl): ncclAllGather through the C ABI on the engine stream; otherwise
-    torch.distributed (backend nccl == RCCL, or gloo in the single-GPU / CPU tests)."""
+    """local: [n_local, ...] results of this rank (uint8 NHWC images, or per-image metric rows).  Returns [n_images, ...] on
+    every rank.  Shards may differ by one image; each is padded to the largest shard for the collective.
+
+    Engine with an RCCL communicator (attach / init_rccl): DeviceArray in -> DeviceArray out (engine-owned buffers,
+    ncclAllGather on the engine stream), host numpy in -> numpy out.  Otherwise torch.distributed (torch tensors; DeviceArrays
+    and numpy arrays are staged through the host -- the several-ranks-on-one-GPU / CPU test configuration)."""
+    from .engine import DeviceArray
+    if engine is not None and getattr(engine, "rccl", False):
+        if hasattr(local, "data_ptr"):           # a torch tensor from an older caller: stage through the host
+            return _gather_rccl(engine, local.cpu().numpy(), n_images, rank, world)
+        return _gather_rccl(engine, local, n_images, rank, world)
     import torch
     import torch.distributed as dist
-    if engine is not None and getattr(engine, "rccl", False):
-        sizes = [shard_range(n_images, r, world) for r in range(world)]
-        mx = max(hi - lo for lo, hi in sizes)
-        pad = local
-        if local.shape[0] < mx:
-            pad = torch.cat([local, local.new_zeros((mx - local.shape[0],) + tuple(local.shape[1:]))], 0)
-        pad = pad.contiguous()
-        recv = torch.empty((world,) + tuple(pad.shape), dtype=pad.dtype, device=pad.device)
-        torch.cuda.current_stream(pad.device).synchronize()          # `pad` may have been produced on torch's stream
-        engine._check(engine.lib.dpir_allgather_results(engine.h, pad.data_ptr(), recv.data_ptr(), pad.numel() * pad.element_size()))
-        engine.sync()
-        return torch.cat([recv[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
+    kind = "torch"
+    if isinstance(local, DeviceArray):
+        kind, eng0 = "device", local.engine
+        local = torch.from_numpy(local.numpy() if local.shape[0] else np.zeros(local.shape, local.dtype))
+    elif isinstance(local, np.ndarray):
+        kind, local = "numpy", torch.from_numpy(np.ascontiguousarray(local))
+
+    def back(t):
+        if kind == "device":
+            return eng0.to_device(t.cpu().numpy())
+        return t.cpu().numpy() if kind == "numpy" else t
     if world == 1 and not (dist.is_available() and dist.is_initialized()):
-        return local
+        return back(local)
     sizes = [shard_range(n_images, r, world) for r in range(world)]
     mx = max(hi - lo for lo, hi in sizes)
     pad = local
@@ -133,10 +229,12 @@ def all_gather_results(local, n_images: int, rank: int, world: int, engine=None)
     pad = pad.contiguous()
     if dist.get_backend() == "gloo" and pad.is_cuda:       # gloo stages through the host (tests on one GPU)
         pad = pad.cpu()
+    elif dist.get_backend() == "nccl" and not pad.is_cuda:  # a process group created with "nccl" has no CPU backend
+        pad = pad.cuda()
     bufs = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(bufs, pad)
     out = torch.cat([bufs[r][: hi - lo] for r, (lo, hi) in enumerate(sizes)], 0)
-    return out.to(local.device)
+    return back(out.to(local.device))
 
 
 def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int, world: int, image_offset: int = 0, seed: int = 0,
@@ -149,15 +247,13 @@ def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int
     Device noise is keyed by the global image index (image_offset + lo + b), so the gathered result is independent of
     `world`.  Host noise (parity mode) must be pre-drawn for the GLOBAL batch: host_noise = (init, n1, n2[, nrp]) as returned
     by restore.draw_host_noise for the global shape; each rank uploads its image slice.
-    Returns (uint8 [n_images, H, W, 3] on every rank as a torch tensor on this rank's device, local fp32 DeviceArray)."""
-    import numpy as np
-    import torch
+    Returns (uint8 [n_images, H, W, 3] on every rank as an engine-owned DeviceArray, local fp32 DeviceArray)."""
     from . import restore
     n = y.shape[0]
     lo, hi = shard_range(n, rank, world)
     sl = slice(lo, hi)
     H, W = y.shape[2] * cfg.sf, y.shape[3] * cfg.sf
-    out_u8 = torch.empty((hi - lo, H, W, 3), dtype=torch.uint8, device=f"cuda:{engine.device}")
+    out_u8 = engine.empty((hi - lo, H, W, 3), np.uint8)
     if hi > lo:
         kw = dict(k=None if k is None else np.ascontiguousarray(k[sl]), mask=None if mask is None else np.ascontiguousarray(mask[sl]),
                   labels=None if labels is None else np.asarray(labels)[sl], seed=seed, image_offset=image_offset + lo,

@@ -124,7 +124,7 @@ def main(argv=None):
     ap.add_argument("--device", type=int, default=None, help="HIP ordinal (default: LOCAL_RANK, else 0)")
     ap.add_argument("--max-sweeps", type=int, default=0)
     ap.add_argument("--num-gpus", type=int, default=0, help="shard every batch over this many GPUs (one process per GPU)")
-    ap.add_argument("--dist-backend", default="nccl", help="torch.distributed backend of the result all-gather (nccl = RCCL)")
+    ap.add_argument("--dist-backend", default="rccl", help="result collective: rccl (the C ABI's ncclAllGather binding, default) | nccl | gloo (torch.distributed)")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(asctime)s %(message)s")
     config = parse_config(args.opt)
@@ -140,8 +140,7 @@ def main(argv=None):
     np.random.seed(config.seed)
     eng = Engine(args.device if args.device is not None else local_rank)
     eng.set_precision(str(config.get("engine_precision", "f16x3")))      # before load_state_dict: selects the weight packing
-    if os.environ.get("DIFFPIR_COLLECTIVE") == "rccl":
-        ddist.init_rccl(eng, rank, world)
+    ddist.attach(eng)                      # rccl: ncclCommInitRank on this engine's device
 
     model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),
                         num_channels=128, num_res_blocks=1, attention_resolutions="16") \
@@ -181,8 +180,16 @@ def main(argv=None):
             n_b, H, W = gt.shape[0], gt.shape[1], gt.shape[2]
             k_all, mask_all = make_operators(config, n_b, i0, H, W)      # every rank draws the same operators (seeded numpy)
             lo, hi = ddist.shard_range(n_b, rank, world)                 # this rank's images of the batch
-            per_img = np.zeros(0)
-            u8_local = torch.empty((hi - lo, H, W, 3), dtype=torch.uint8, device=f"cuda:{eng.device}")
+            per_img = np.zeros((0, 2))
+            u8_local = eng.empty((hi - lo, H, W, 3), np.uint8)          # engine-owned result buffer (send side of the all-gather)
+            drawn = None
+            if noise == "host":
+                # EVERY rank draws the global batch's noise, also a rank whose shard is empty (ragged last batch with fewer images
+                # than ranks): the shared generator must advance identically everywhere or later batches depend on the world size
+                _, steps, _ = restore._steps(cfg)
+                nf = lambda shape: torch.randn(tuple(shape), generator=host_gen).numpy()
+                full = restore.draw_host_noise(nf, steps, (n_b, 3, H, W), cfg.eta != 0, repaint=cfg.generate_mode == "repaint")
+                drawn = [None if a is None else (np.ascontiguousarray(a[lo:hi]) if a.ndim == 4 else np.ascontiguousarray(a[:, lo:hi])) for a in full]
             if hi > lo:
                 sl = slice(lo, hi)
                 # degradation on the device (dpir_degrade): blur / down-sampling / masking + AWGN, device Philox noise keyed by the
@@ -190,19 +197,13 @@ def main(argv=None):
                 y, ops = dgr.degrade(eng, config.task, gt[sl], k=None if k_all is None else k_all[sl], mask=None if mask_all is None else mask_all[sl],
                                      noise_level_img=config.noise_level_img, sf=config.sf, sr_mode=config.sr_mode, seed=config.seed + 1,
                                      image_offset=i0 + lo)
-                drawn = None
-                if noise == "host":
-                    _, steps, _ = restore._steps(cfg)
-                    nf = lambda shape: torch.randn(tuple(shape), generator=host_gen).numpy()
-                    full = restore.draw_host_noise(nf, steps, (n_b, 3, H, W), cfg.eta != 0, repaint=cfg.generate_mode == "repaint")
-                    drawn = [None if a is None else (np.ascontiguousarray(a[sl]) if a.ndim == 4 else np.ascontiguousarray(a[:, sl])) for a in full]
                 out_f32 = restore.restore_batch(eng, cfg, y, k=ops.get("k"), mask=ops.get("mask"), noise_source=noise, predrawn=drawn,
                                                 seed=config.seed, image_offset=i0 + lo, use_graph=use_graph, out_u8=u8_local, _cache=cache,
                                                 skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False)))
                 psnr_i, psnr_y_i = dgr.metrics(eng, out_f32, ops["gt"])            # dpir_metrics: per-image PSNR / PSNR-Y
                 per_img = np.stack([psnr_i, psnr_y_i], 1).astype(np.float64)
             u8 = ddist.all_gather_results(u8_local, n_b, rank, world, engine=eng)           # the one collective of the path
-            allm = ddist.all_gather_results(torch.from_numpy(per_img.reshape(-1, 2)), n_b, rank, world).numpy()
+            allm = ddist.all_gather_results(per_img.reshape(-1, 2), n_b, rank, world, engine=eng)      # per-image PSNR rows (host numpy)
             p, p_y = float(np.mean(allm[:, 0])), float(np.mean(allm[:, 1]))
             psnrs.append(p * n_b)
             psnrs_y.append(p_y * n_b)

@@ -221,10 +221,15 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* step
  *   dpir_comm_unique_id : rank 0 creates the 128-byte ncclUniqueId; the host side ships it to the other ranks;
  *   dpir_comm_init      : ncclCommInitRank on this engine's device;
  *   dpir_allgather_results(send [bytes_per_rank], recv [world * bytes_per_rank]) : ncclAllGather(ncclUint8);
+ *   dpir_comm_allreduce_max / dpir_comm_barrier : the two rendezvous primitives a multi-GPU driver needs around its timed region
+ *                         (MAX over ranks of one host double; a barrier is the same exchange with the value ignored) -- with
+ *                         them the N-GPU launch needs no other communication library;
  *   dpir_comm_destroy   : also done by dpir_destroy. */
 int dpir_comm_unique_id(void* id128_out);
 int dpir_comm_init(dpir_engine* e, int world, int rank, const void* id128);
 int dpir_allgather_results(dpir_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
+int dpir_comm_allreduce_max(dpir_engine* e, double* value_inout);
+int dpir_comm_barrier(dpir_engine* e);
 int dpir_comm_destroy(dpir_engine* e);
 
 /* ---- degradation synthesis and metrics: the steps either side of the loop ------------------ */

@@ -1,0 +1,98 @@
+"""Golden vectors from the LIVE reference for the two large topologies and for loops long enough that the flat north-star bar
+(|dPSNR| <= 1e-3 dB) holds without any conditioning allowance:
+
+  * `in256_64_*`   : guided_diffusion UNetModel.forward, `256x256_diffusion_uncond` hyper-parameters (main_ddpir.py:225-230),
+                     one 64x64 image -- pins the oracle restatement of the ImageNet-256 topology (16 attention blocks,
+                     2 ResBlocks per level) to the reference itself;
+  * `in512cc_64_*` : the 512x512 class-conditional topology (script_util.py:149-150, labels through model_kwargs), one 64x64
+                     image with a label (the 7-level ladder bottoms out at 1x1);
+  * `c3_*`         : BASELINE config 3 at full size: ImageNet-256 topology, 64^2 -> 256^2 x4 SISR with the bicubic PSF
+                     (kernels_bicubicx234[0, 2]), lambda 6, zeta 0.25, B=1, 20 NFE through model_fn -> data_solution -> re-noise;
+  * `c5_*`         : BASELINE config 5 at full size: 512^2 class-conditional topology, 128^2 -> 512^2, label 417, B=1, 8 NFE.
+  For the loops the reference's OWN fp32 rounding noise (distance to the same loop with the closed-form prox in float64) is
+  stored next to the output, as in fullsize.npz.
+
+TEST INFRASTRUCTURE ONLY; build container only (needs /root/reference).
+    python -m oracle.gen_golden_long   ->  tests/golden/long.npz
+"""
+import os
+import sys
+import time
+import numpy as np
+import torch
+
+from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+C3_NFE, C5_NFE = 20, 8
+
+
+def seeded_noise_fn(seed):
+    g = torch.Generator().manual_seed(seed)
+    return lambda like: torch.randn(like.shape, generator=g, dtype=torch.float32)
+
+
+def loop_case(out, tag, hp, sd, model, diffusion, size, nfe, seed_case, seed_noise, label=None):
+    from diffpir_amd import synth
+    kb = np.load(os.path.join(OUT, "operators.npz"))["k_bic4"][None, None].astype(np.float32)
+    case = synth.make_case("sr", 1, size, size, seed=seed_case, sf=4)
+    cfg = do.LoopConfig("sr", nfe, 12.75 / 255, 6.0, 0.25, sf=4)
+    y, k = torch.from_numpy(case["y"]), torch.from_numpy(kb)
+    lab = None if label is None else torch.tensor([label])
+    t0 = time.time()
+    with torch.no_grad():
+        ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), y_label=lab).numpy()
+        print(tag, "live reference", round(time.time() - t0, 1), "s", flush=True)
+        ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), y_label=lab).numpy()
+        exact = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), exact_prox=True, y_label=lab).numpy()
+    d = ref - exact
+    gt = case["gt"]
+    gap_floor = abs(do.psnr_batch(torch.from_numpy(ref * 2 - 1), torch.from_numpy(gt * 2 - 1)) -
+                    do.psnr_batch(torch.from_numpy(exact * 2 - 1), torch.from_numpy(gt * 2 - 1)))
+    out.update({f"{tag}_y": case["y"], f"{tag}_gt_seed": np.array(seed_case), f"{tag}_out": ref, f"{tag}_seed": np.array(seed_noise),
+                f"{tag}_nfe": np.array(nfe), f"{tag}_floor_max": np.array(np.abs(d).max()),
+                f"{tag}_floor_rms": np.array(np.sqrt(np.mean(d * d))), f"{tag}_floor_dpsnr": np.array(float(gap_floor))})
+    if label is not None:
+        out[f"{tag}_label"] = np.array([label])
+    print(f"{tag} {nfe}-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()),
+          "| reference vs exact-prox loop: max", float(np.abs(d).max()), "rms", float(np.sqrt(np.mean(d * d))),
+          "|dPSNR|", float(gap_floor), flush=True)
+
+
+def main():
+    torch.set_num_threads(8)
+    out = {}
+    only = set(sys.argv[1:])
+
+    hp = uo.imagenet256_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    model, diffusion = live_reference.build_unet(hp, sd)
+    x = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(31))
+    t = torch.tensor([333])
+    with torch.no_grad():
+        ref = model(x, t).numpy()
+        ora = uo.unet_forward(sd, hp, x, t).numpy()
+    out.update(in256_64_x_seed=np.array(31), in256_64_t=t.numpy(), in256_64_out=ref)
+    print("imagenet-256 topology @64^2: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), flush=True)
+    if not only or "c3" in only:
+        loop_case(out, "c3", hp, sd, model, diffusion, 256, C3_NFE, 3, 71)
+    del model, sd
+
+    hp = uo.imagenet512_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    model, diffusion = live_reference.build_unet(hp, sd)
+    x = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(32))
+    t, lab = torch.tensor([480]), torch.tensor([417])
+    with torch.no_grad():
+        ref = model(x, t, y=lab).numpy()
+        ora = uo.unet_forward(sd, hp, x, t, lab).numpy()
+    out.update(in512cc_64_x_seed=np.array(32), in512cc_64_t=t.numpy(), in512cc_64_label=lab.numpy(), in512cc_64_out=ref)
+    print("512 class-cond topology @64^2: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), flush=True)
+    if not only or "c5" in only:
+        loop_case(out, "c5", hp, sd, model, diffusion, 512, C5_NFE, 5, 72, label=417)
+    np.savez_compressed(os.path.join(OUT, "long.npz"), **out)
+    print("wrote", os.path.join(OUT, "long.npz"), flush=True)
+
+
+if __name__ == "__main__":
+    main()

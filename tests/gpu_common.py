@@ -54,7 +54,7 @@ def oracle_pair(key, sd, hp, ocfg, y, k, seed, y_label=None):
     return _ORACLE_CACHE[key]
 
 
-def fft_prox_parity(out, ref, gt, label, exact=None, floor=None):
+def fft_prox_parity(out, ref, gt, label, exact=None, floor=None, nfe=None, floor_dpsnr=None):
     """Parity gate for loops through the FFT data-fidelity step.
 
     The reference's closed form (utils_sisr.py:65-75) divides a near-cancelling difference by alpha = tau (7e-7 at the first
@@ -67,7 +67,9 @@ def fft_prox_parity(out, ref, gt, label, exact=None, floor=None):
       * engine vs reference   : rms <= floor rms, max <= 1.5 x floor max  (closer to the reference than the reference is to exact)
       * engine vs exact       : rms <= 2 x floor rms   (the triangle-inequality consequence of the line above; the rounding noise of
         any fp32 evaluation lies along the same few ill-conditioned spectral modes, so the two deviations can add coherently --
-        measured on ImageNet-256 sr x4: reference-vs-exact 2.0e-3, engine-vs-reference 1.2e-3, engine-vs-exact 2.9e-3)"""
+        measured on ImageNet-256 sr x4: reference-vs-exact 2.0e-3, engine-vs-reference 1.2e-3, engine-vs-exact 2.9e-3)
+    Runs of nfe >= 20 (the first steps' rounding noise has been contracted) get NO allowance: |dPSNR| <= 1e-3 dB flat and
+    max <= 1.0 x floor max.  Runs of nfe >= 8 keep the 1.5 x on the maximum but also get the flat dPSNR bar."""
     from diffpir_amd import restore
     if floor is None:
         d = ref - exact
@@ -77,7 +79,7 @@ def fft_prox_parity(out, ref, gt, label, exact=None, floor=None):
     gap = abs(restore.psnr_batch(out * 2 - 1, gt * 2 - 1) - restore.psnr_batch(ref * 2 - 1, gt * 2 - 1))
     msg = (f"{label}: engine-vs-reference max {emax:.3e} rms {erms:.3e} | reference-vs-exact (its own fp32 noise) max {floor[0]:.3e} "
            f"rms {floor[1]:.3e} | |dPSNR| {gap:.2e} dB")
-    gap_floor = 0.0
+    gap_floor = 0.0 if floor_dpsnr is None else float(floor_dpsnr)
     if exact is not None:
         x = out - exact
         xrms = float(np.sqrt(np.mean(x * x)))
@@ -85,6 +87,8 @@ def fft_prox_parity(out, ref, gt, label, exact=None, floor=None):
         msg += f" | engine-vs-exact rms {xrms:.3e} | reference's own |dPSNR| vs exact {gap_floor:.2e} dB"
         assert xrms <= 2.0 * floor[1] + 1e-6, msg
     print(msg)
-    assert gap <= max(1e-3, gap_floor), msg
-    assert erms <= floor[1] + 1e-6 and emax <= 1.5 * floor[0] + 1e-5, msg
+    long_run = nfe is not None and nfe >= 20
+    flat_bar = nfe is not None and nfe >= 8
+    assert gap <= (1e-3 if flat_bar else max(1e-3, gap_floor)), msg
+    assert erms <= floor[1] + 1e-6 and emax <= (1.0 if long_run else 1.5) * floor[0] + 1e-5, msg
     return emax, erms, gap

@@ -49,6 +49,32 @@ def test_sharded_results_equal_single_process(n_images):
     assert ret[0] == ref and ret[1] == ref
 
 
+def _worker_api(rank, world, port, ret):
+    """The module-level flow bench.py / the YAML driver use: init -> attach -> barrier / max_over_ranks / gather of host rows -> shutdown."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      DIFFPIR_COLLECTIVE="gloo")
+    r, _, w = ddist.init()                      # DIFFPIR_COLLECTIVE overrides the default (rccl needs a GPU engine)
+    ddist.attach(None)
+    ddist.barrier()
+    mx = ddist.max_over_ranks(1.0 + rank)
+    lo, hi = ddist.shard_range(5, r, w)
+    rows = np.stack([np.arange(lo, hi, dtype=np.float64), -np.arange(lo, hi, dtype=np.float64)], 1)
+    allm = ddist.all_gather_results(rows, 5, r, w)
+    ret[rank] = (mx, allm.tolist(), ddist.collective_name())
+    ddist.shutdown()
+
+
+def test_module_level_flow_on_gloo_world_2():
+    world = 2
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker_api, args=(world, _free_port(), ret), nprocs=world, join=True)
+    want = [[float(i), -float(i)] for i in range(5)]
+    for rnk in range(world):
+        mx, rows, name = ret[rnk]
+        assert mx == 2.0 and rows == want and "gloo" in name
+
+
 def test_shard_ranges_partition_the_batch():
     for n in (1, 7, 16, 256):
         for w in (1, 2, 4, 8):

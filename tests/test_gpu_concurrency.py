@@ -55,10 +55,8 @@ def test_concurrent_engines_equal_sequential_engines():
 def test_register_fft_probe_without_packed_fp32_is_reproducible_beside_f16_convs():
     import diffpir_amd
     ea, ef = diffpir_amd.Engine(0), diffpir_amd.Engine(0)
-    lib = ea.lib
-    lib.dpir_debug_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_double)]
-    for fn in (lib.dpir_debug_victim_fft_pk, lib.dpir_debug_victim_fft_nopk):
-        fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
+    from diffpir_amd import _lib
+    lib = _lib.load_debug()              # development probes: their own library (include/diffpir_debug.h)
     conv = (8, 128, 128, 256, 256, 3, 0, 1, 2)                     # conv6 3x3 128 -> 128 @256^2, f16x3
     stop, ms = [False], C.c_double(0)
 

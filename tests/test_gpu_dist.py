@@ -33,6 +33,7 @@ def _run(rank, world, port, n, noise, ret):
     from tests.gpu_common import make_model, seeded_noise_fn_np
     r, _, w = ddist.init("gloo")
     eng = diffpir_amd.Engine(0)
+    ddist.attach(eng)
     make_model(eng, uo.tiny_hp())
     cfg = restore.LoopConfig(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3, eta=0.5 if noise == "host" else 0.0)
     case = _case(n)
@@ -42,7 +43,7 @@ def _run(rank, world, port, n, noise, ret):
         drawn = restore.draw_host_noise(seeded_noise_fn_np(77), steps, (n, 3, 32, 32), True)
     u8, _ = ddist.restore_sharded(eng, cfg, case["y"], k=case["k"], rank=r, world=w, image_offset=100, seed=9, use_graph=True,
                                   noise_source=noise, host_noise=drawn)
-    ret[rank] = u8.cpu().numpy().tobytes()
+    ret[rank] = u8.numpy().tobytes()                # engine-owned DeviceArray
     ddist.shutdown()
     eng.close()
 
@@ -58,31 +59,69 @@ def test_two_ranks_on_one_gpu_equal_one_rank(n, noise):
     assert two[0] == one[0] and two[1] == one[0]
 
 
-def test_rccl_allgather_through_the_c_abi_world_1():
-    """dpir_comm_* / dpir_allgather_results bind ncclAllGather from librccl.so (dlopen).  One GPU admits one rank per
-    communicator, so this checks the binding, the stream ordering and the padding / slicing logic at world = 1."""
-    import torch
+def test_rccl_collectives_through_the_c_abi_world_1():
+    """dpir_comm_* / dpir_allgather_results / dpir_comm_barrier / dpir_comm_allreduce_max bind RCCL from librccl.so (dlopen).  One
+    GPU admits one rank per communicator, so this checks the binding, the stream ordering, the engine-owned buffers and the
+    padding / slicing logic at world = 1 -- through dist.init / attach, the calls the multi-GPU launch makes (the DEFAULT
+    collective: no torch.distributed process group exists in this process)."""
     import diffpir_amd
     from diffpir_amd import dist as ddist
+    from diffpir_amd.engine import DeviceArray
+    os.environ.update(DIFFPIR_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    os.environ.pop("DIFFPIR_COLLECTIVE", None)
     eng = diffpir_amd.Engine(0)
     try:
-        ddist.init_rccl(eng, 0, 1)
-        local = torch.randint(0, 256, (3, 8, 8, 3), dtype=torch.uint8, device="cuda:0")
+        r, _, w = ddist.init()
+        assert (r, w) == (0, 1)
+        ddist.attach(eng)
+        assert "C ABI" in ddist.collective_name()
+        import torch.distributed as tdist
+        assert not tdist.is_initialized()
+        host = np.random.default_rng(0).integers(0, 256, (3, 8, 8, 3), dtype=np.uint8)
+        local = eng.to_device(host)
         out = ddist.all_gather_results(local, 3, 0, 1, engine=eng)
-        assert out.shape == local.shape and torch.equal(out, local) and out.data_ptr() != local.data_ptr()
+        assert isinstance(out, DeviceArray) and out.ptr != local.ptr and np.array_equal(out.numpy(), host)
+        rows = np.arange(6, dtype=np.float64).reshape(3, 2)               # per-image metric rows: host numpy in, numpy out
+        assert np.array_equal(ddist.all_gather_results(rows, 3, 0, 1, engine=eng), rows)
+        ddist.barrier()
+        assert ddist.max_over_ranks(3.25) == 3.25
+        ddist.shutdown()
     finally:
+        os.environ.pop("DIFFPIR_FORCE_DIST", None)
         eng.close()
 
 
-def test_bench_launch_line_with_the_nccl_backend_world_1():
+@pytest.mark.parametrize("collective", ["rccl", "nccl"])
+def test_yaml_driver_with_a_process_group_world_1(tmp_path, collective):
+    """`python -m diffpir_amd.main_ddpir` under DIFFPIR_FORCE_DIST=1: the driver's multi-GPU code path (sharding, the uint8
+    all-gather, the per-image PSNR gather -- a HOST float64 array, which a torch "nccl" group cannot move without staging it on
+    the device) at world = 1, on the default C-ABI collective and on torch.distributed's nccl backend."""
+    import subprocess
+    import sys
+    import yaml
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = yaml.safe_load(open(os.path.join(root, "configs", "engine_example.yaml")))
+    cfg.update(iter_num=3, batch_size=2, task="deblur")
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    env = dict(os.environ, DIFFPIR_FORCE_DIST="1", DIFFPIR_COLLECTIVE=collective, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "diffpir_amd.main_ddpir", "--opt", str(p), "--synthetic", "3", "--max-sweeps", "1"],
+                       cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "Average PSNR(RGB)" in r.stdout + r.stderr
+
+
+def test_bench_launch_line_on_the_default_collective_world_1():
     """The driver's multi-GPU launch line (`python -m torch.distributed.run ... bench.py --gpus N`) on the one GPU of this box:
-    DIFFPIR_FORCE_DIST=1 makes rank 0 join a 1-rank RCCL group, so process-group init, the barrier, the uint8 all-gather and the
-    MAX all-reduce of the timing run through backend "nccl" exactly as they do at N > 1."""
+    DIFFPIR_FORCE_DIST=1 makes rank 0 create a 1-rank RCCL communicator through the C ABI, so the rendezvous, the barrier, the
+    uint8 all-gather and the MAX all-reduce of the timing run exactly as they do at N > 1 (DIFFPIR_COLLECTIVE unset)."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, DIFFPIR_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("DIFFPIR_COLLECTIVE", None)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
            "--nfe", "6", "--batch", "4", "--no-cpu-baseline", "--no-c3", "--no-alt"]
@@ -90,6 +129,7 @@ def test_bench_launch_line_with_the_nccl_backend_world_1():
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["global_batch"] == 4
+    assert "C ABI" in line["config"]["collective"]
 
 
 def test_bench_launch_line_two_ranks_on_one_gpu_gloo():

@@ -89,6 +89,61 @@ def test_c2_100_nfe_vs_oracle(ffhq):
     assert gap <= 1e-3 and err < 1e-3          # the early steps' rounding noise is gone by 100 NFE: a tight pixel bound holds
 
 
+_B16 = {}
+
+
+def _b16_inputs():
+    if not _B16:
+        g = torch.Generator().manual_seed(77)
+        _B16["x"] = torch.randn((16, 3, 256, 256), generator=g)
+        _B16["t"] = torch.randint(0, 1000, (16,), generator=g)
+        _B16["ref"] = {}
+    return _B16
+
+
+def test_ffhq_forward_at_the_benched_batch_b16(ffhq):
+    """The bench runs B = 16: conv6 picks other split-K factors / statistics routes for the <= 64^2 layers than at B <= 2, the fused
+    low-resolution prologue owns 512 (image, group) workgroups and conv5 emits operand planes for 16 images.  Engine forward at
+    B = 16 (a different timestep per image) against the oracle on three of the images, and against the same engine at B = 2."""
+    e, sd, precision = ffhq
+    c = _b16_inputs()
+    out = e.unet_forward(e.to_device(c["x"].numpy()), c["t"].numpy()).numpy()
+    worst = 0.0
+    for i in (0, 9, 15):
+        if i not in c["ref"]:
+            c["ref"][i] = uo.unet_forward(sd, uo.ffhq_hp(), c["x"][i:i + 1], c["t"][i:i + 1]).numpy()
+        worst = max(worst, rel_err(out[i:i + 1], c["ref"][i]))
+    out2 = e.unet_forward(e.to_device(c["x"][8:10].numpy()), c["t"][8:10].numpy()).numpy()
+    inv = rel_err(out[8:10], out2)
+    print(f"ffhq 256^2 forward B=16 [{precision}]: worst rel err vs oracle (images 0, 9, 15) {worst:.3e}; B=16 vs B=2 on images 8-9 {inv:.3e}")
+    assert worst < TOL_LAYER and inv < TOL_LAYER
+
+
+def test_c2_loop_at_the_benched_batch_b16_6nfe(ffhq):
+    """BASELINE config 2's batch (B = 16) through the replayed graph, 6 NFE, host noise drawn for the whole batch in the
+    reference's order; the oracle restores images 3 and 12 with the same per-image noise slices."""
+    e, sd, precision = ffhq
+    B, sub = 16, [3, 12]
+    case = synth.make_case("deblur", B, 256, 256, seed=13, ksize=61)
+    cfg = restore.LoopConfig(task="deblur", iter_num=6, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(66),
+                                use_graph=True).numpy()
+
+    def sliced(seed):
+        g = torch.Generator().manual_seed(seed)
+        return lambda like: torch.randn((B,) + tuple(like.shape[1:]), generator=g, dtype=torch.float32)[sub]
+    key = "c2_b16_6nfe"
+    from tests import gpu_common
+    if key not in gpu_common._ORACLE_CACHE:
+        ocfg = do.LoopConfig("deblur", 6, 12.75 / 255, 7.0, 0.3)
+        ty, tk = torch.from_numpy(case["y"][sub]), torch.from_numpy(case["k"][sub])
+        ref = do.restore(sd, uo.ffhq_hp(), ocfg, ty, k=tk, noise_fn=sliced(66)).numpy()
+        exact = do.restore(sd, uo.ffhq_hp(), ocfg, ty, k=tk, noise_fn=sliced(66), exact_prox=True).numpy()
+        gpu_common._ORACLE_CACHE[key] = (ref, exact)
+    ref, exact = gpu_common._ORACLE_CACHE[key]
+    fft_prox_parity(out[sub], ref, case["gt"][sub], f"C2 B=16 6-NFE, images 3 and 12 [{precision}] vs oracle", exact=exact)
+
+
 def test_c4_motion_deblur_vs_oracle(ffhq):
     """BASELINE config 4's per-GPU work: FFHQ topology, 256x256, a NON-symmetric 61x61 motion PSF per image (random-walk line; the
     `motionblur` package is not available offline), through the replayed graph; 4 NFE at B = 2 against the oracle."""
@@ -133,6 +188,37 @@ def test_imagenet256_topology_at_256_layers(imagenet):
     assert e.unet_flops(256, 256) == pytest.approx(2239.67e9, rel=1e-3)
 
 
+def test_imagenet256_forward_b4_at_256(imagenet):
+    """Config 3's network at B = 4, 256^2 (other split-K factors than B = 1): image 2 against the oracle."""
+    e, sd, precision = imagenet
+    g = torch.Generator().manual_seed(23)
+    x = torch.randn((4, 3, 256, 256), generator=g)
+    t = torch.tensor([900, 611, 42, 3])
+    out = e.unet_forward(e.to_device(x.numpy()), t.numpy()).numpy()
+    key = "in256_b4_img2"
+    from tests import gpu_common
+    if key not in gpu_common._ORACLE_CACHE:
+        gpu_common._ORACLE_CACHE[key] = uo.unet_forward(sd, uo.imagenet256_hp(), x[2:3], t[2:3]).numpy()
+    err = rel_err(out[2:3], gpu_common._ORACLE_CACHE[key])
+    print(f"imagenet-256 @256^2 B=4 [{precision}]: image 2 rel err vs oracle {err:.3e}")
+    assert err < TOL_LAYER
+
+
+def test_c3_20nfe_matches_live_reference_fixture(imagenet, golden):
+    """BASELINE config 3 at full size for 20 NFE (B = 1) against the LIVE reference (tests/golden/long.npz): long enough that the
+    flat north-star bar |dPSNR| <= 1e-3 dB is asserted with no conditioning allowance."""
+    e, sd, precision = imagenet
+    g = golden("long")
+    kb = golden("operators")["k_bic4"][None, None].astype(np.float32)
+    nfe = int(g["c3_nfe"])
+    gt = synth.make_case("sr", 1, 256, 256, seed=int(g["c3_gt_seed"]), sf=4)["gt"]
+    cfg = restore.LoopConfig(task="sr", iter_num=nfe, lambda_=6.0, zeta=0.25, sf=4)
+    out = restore.restore_batch(e, cfg, g["c3_y"], k=kb, noise_source="host", noise_fn=seeded_noise_fn_np(int(g["c3_seed"])),
+                                use_graph=True).numpy()
+    fft_prox_parity(out, g["c3_out"], gt, f"C3 sr x4 {nfe}-NFE [{precision}] vs LIVE reference", nfe=nfe,
+                    floor=(float(g["c3_floor_max"]), float(g["c3_floor_rms"])), floor_dpsnr=float(g["c3_floor_dpsnr"]))
+
+
 def test_c3_sr4_loop_full_size_vs_oracle(imagenet, golden):
     """Config 3 in miniature: ImageNet-256 topology, 64^2 -> 256^2, x4 bicubic PSF (kernels_bicubicx234[0,2]), 3 NFE, graph on."""
     e, sd, precision = imagenet
@@ -175,6 +261,15 @@ def test_imagenet512_class_conditional_forward(precision):
             r, exact = oracle_pair("c5_sr4_2nfe", sd, hp, do.LoopConfig("sr", 2, 12.75 / 255, 6.0, 0.25, sf=4), case["y"], kb, 65,
                                    y_label=torch.from_numpy(lab))
             fft_prox_parity(o, r, case["gt"], "C5 512^2 class-cond sr x4 2-NFE [f16x3] vs oracle", exact=exact)
+            # config 5 for 8 NFE against the LIVE reference fixture: the flat 1e-3 dB bar, no conditioning allowance
+            g = np.load(os.path.join(os.path.dirname(__file__), "golden", "long.npz"))
+            nfe = int(g["c5_nfe"])
+            gt = synth.make_case("sr", 1, 512, 512, seed=int(g["c5_gt_seed"]), sf=4)["gt"]
+            cfg = restore.LoopConfig(task="sr", iter_num=nfe, lambda_=6.0, zeta=0.25, sf=4)
+            o = restore.restore_batch(e, cfg, g["c5_y"], k=kb, labels=g["c5_label"], noise_source="host",
+                                      noise_fn=seeded_noise_fn_np(int(g["c5_seed"])), use_graph=True).numpy()
+            fft_prox_parity(o, g["c5_out"], gt, f"C5 512^2 class-cond sr x4 {nfe}-NFE [f16x3] vs LIVE reference", nfe=nfe,
+                            floor=(float(g["c5_floor_max"]), float(g["c5_floor_rms"])), floor_dpsnr=float(g["c5_floor_dpsnr"]))
     finally:
         e.close()
 

@@ -69,11 +69,14 @@ def test_library_exports_every_declared_symbol():
     assert not missing, missing
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert lib.dpir_version() == 1
-    # the development-only header (probes and the isolated conv bench; not part of the drop-in boundary) must resolve as well
+    # the development-only header (probes and the isolated conv bench) resolves from its OWN library; the product library exports
+    # none of it
     dbg = open(os.path.join(ROOT, "include", "diffpir_debug.h")).read()
     dbg_syms = set(re.findall(r"\b(dpir_debug_[a-z0-9_]+)\s*\(", dbg))
     assert len(dbg_syms) >= 5
-    assert not [n for n in sorted(dbg_syms) if not hasattr(lib, n)]
+    assert not [n for n in sorted(dbg_syms) if hasattr(lib, n)], "development probes leaked into libdiffpir_hip.so"
+    dlib = _lib.load_debug()
+    assert not [n for n in sorted(dbg_syms) if not hasattr(dlib, n)]
 
 
 def test_struct_layouts_match_header():

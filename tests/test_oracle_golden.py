@@ -22,6 +22,18 @@ def test_unet_forward_matches_reference(golden, tag, hp):
     np.testing.assert_allclose(out.numpy(), g["out"], rtol=0, atol=1e-5)
 
 
+@pytest.mark.parametrize("tag,hp", [("in256_64", uo.imagenet256_hp()), ("in512cc_64", uo.imagenet512_hp())])
+def test_large_topologies_match_live_reference_fixture(golden, tag, hp):
+    """The ImageNet-256 (2 ResBlocks / level, 16 attention blocks) and 512x512 class-conditional (7 levels, labels) topologies of
+    BASELINE configs 3 and 5: the restatement against the live reference's UNetModel.forward at 64x64 (oracle/gen_golden_long.py)."""
+    g = golden("long")
+    sd = uo.synth_state_dict(hp, 0)
+    x = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(int(g[tag + "_x_seed"])))
+    y = torch.from_numpy(g[tag + "_label"]) if hp.class_cond else None
+    out = uo.unet_forward(sd, hp, x, torch.from_numpy(g[tag + "_t"]), y)
+    np.testing.assert_allclose(out.numpy(), g[tag + "_out"], rtol=0, atol=1e-5)
+
+
 def test_ffhq_topology_counts():
     hp = uo.ffhq_hp()
     spec = uo.state_dict_spec(hp)
