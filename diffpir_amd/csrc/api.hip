@@ -28,17 +28,23 @@ static void prox_release(dpir::ProxState* st);
 
 // f16x3 operand range guard: called where the ABI synchronises anyway (dpir_sync, D2H copies).  A non-zero count means
 // at least that many wave-lanes clamped an activation to the f16 range since the last check: the images are wrong.
-static int check_range(dpir_engine* e) {
+// The failure is STICKY: every later dpir_sync / dpir_d2h / dpir_allgather_results keeps returning DPIR_ERR_RANGE (the device
+// results stay wrong) until the next UNet forward or restoration loop starts (range_clear).
+int dpir_check_range(dpir_engine* e) {
     if (!e->range_ctr || e->precision == 0) return DPIR_OK;
     unsigned long long n = 0;
     if (hipMemcpyAsync(&n, e->range_ctr, sizeof(n), hipMemcpyDeviceToHost, e->stream) != hipSuccess ||
         hipStreamSynchronize(e->stream) != hipSuccess)
         return fail(e, Status{DPIR_ERR_HIP, "reading the operand range counter failed"});
     if (n == 0) return DPIR_OK;
-    (void)hipMemsetAsync(e->range_ctr, 0, sizeof(n), e->stream);
-    return fail(e, Status{DPIR_ERR_RANGE, "f16x3 precision mode: " + std::to_string(n) + " activation lane(s) exceeded the f16 operand range "
-                                          "(|v| > 65000 or NaN) and were clamped -- results are invalid; rerun with precision f32 "
-                                          "(engine_precision: f32)"});
+    return fail(e, Status{DPIR_ERR_RANGE, std::string(e->precision == 2 ? "f16x1" : "f16x3") + " precision mode: " + std::to_string(n) +
+                                          " activation lane(s) exceeded the f16 operand range (|v| > 65000 or NaN) and were clamped since the "
+                                          "last forward / loop started -- results are invalid; rerun with precision f32 (engine_precision: f32)"});
+}
+static int check_range(dpir_engine* e) { return dpir_check_range(e); }
+// a new forward / loop starts a new accounting period (stream-ordered)
+static void range_clear(dpir_engine* e) {
+    if (e->range_ctr && e->precision != 0) (void)hipMemsetAsync(e->range_ctr, 0, sizeof(unsigned long long), e->stream);
 }
 static int ilog2u(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -218,6 +224,7 @@ int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, con
     if (!e || !x || !t_host || !out) return fail(e, invalid("dpir_unet_forward: null argument"));
     (void)hipSetDevice(e->device);
     int *t_dev = nullptr, *y_dev = nullptr;
+    range_clear(e);
     API_TRY(e, upload_ints(e, "api#t", t_host, B, &t_dev));
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     if (y_host && e->net.loaded)
@@ -233,6 +240,7 @@ int dpir_model_fn_xstart(dpir_engine* e, const float* x, int t, float c1, float 
     if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
     std::vector<int64_t> tv(B, t);
     int *t_dev = nullptr, *y_dev = nullptr;
+    range_clear(e);
     API_TRY(e, upload_ints(e, "api#t", tv.data(), B, &t_dev));
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     float* out6 = nullptr;
@@ -529,7 +537,8 @@ int dpir_degrade(dpir_engine* e, const dpir_degrade_desc* d, const uint8_t* gt, 
     if (!nz && d->noise_level_img != 0.f) {
         float* nb = nullptr;
         API_TRY(e, e->ws.getT("degrade#noise", total, &nb));
-        API_TRY(e, launch_randn(s, nb, d->seed, 7, d->image_offset, B, (size_t)3 * h * w));      // Philox stream 7: outside the loop's 0..3 + 4i
+        // Philox stream 2^40: the loop's streams are draw + 4 * step (draw 0..3), so no (seed, image) pair can meet this one
+        API_TRY(e, launch_randn(s, nb, d->seed, 1ull << 40, d->image_offset, B, (size_t)3 * h * w));
         nz = nb;
     }
     const bool inp = d->task == DPIR_TASK_INPAINT;
@@ -695,6 +704,7 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     if ((e->net.desc.num_classes > 0) != (d.labels_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
     const int B = d.B, H = d.H, W = d.W;
     const size_t total = (size_t)B * 3 * H * W;
+    range_clear(e);
     LoopBufs b{};
     API_TRY(e, e->ws.getT("loop#x", total, &b.x));
     API_TRY(e, e->ws.getT("loop#x0", total, &b.x0));

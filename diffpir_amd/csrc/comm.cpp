@@ -7,6 +7,8 @@
 #include <string.h>
 #include <mutex>
 
+int dpir_check_range(dpir_engine* e);     // api.hip: the f16 operand range guard (sticky DPIR_ERR_RANGE)
+
 namespace {
 typedef struct { char internal[128]; } UniqueId;        // ncclUniqueId (rccl.h:43, NCCL_UNIQUE_ID_BYTES 128)
 typedef void* Comm;
@@ -78,6 +80,7 @@ int dpir_comm_init(dpir_engine* e, int world, int rank, const void* id128) {
 int dpir_allgather_results(dpir_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank) {
     if (!e || !send_dev || !recv_dev) return fail(e, DPIR_ERR_INVALID, "dpir_allgather_results: null argument");
     if (!e->comm) return fail(e, DPIR_ERR_STATE, "dpir_allgather_results: dpir_comm_init has not been called");
+    if (int rr = dpir_check_range(e)) return rr;       // never ship clamped (wrong) images to the other ranks
     int rc = g_rccl.AllGather(send_dev, recv_dev, bytes_per_rank, kNcclUint8, e->comm, e->stream);      // stream-ordered behind the loop
     if (rc != 0) return fail(e, DPIR_ERR_HIP, "ncclAllGather: " + g_rccl.what(rc));
     return DPIR_OK;

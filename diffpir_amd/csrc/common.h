@@ -7,6 +7,7 @@
 #include <vector>
 #include <map>
 #include <memory>
+#include <mutex>
 
 #include "../../include/diffpir_engine.h"
 
@@ -38,6 +39,19 @@ struct Status {
     } while (0)
 
 inline Status invalid(const std::string& m) { return Status{DPIR_ERR_INVALID, m}; }
+
+// One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) per kernel AND device.  Engines are driven from several host threads
+// (ctypes releases the GIL), so the lazy first-launch initialisation is a std::call_once, one flag per device ordinal.
+struct LdsAttrOnce {
+    std::once_flag flags[16];
+    hipError_t errs[16] = {};
+    hipError_t set(const void* fn, int bytes) {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+        std::call_once(flags[dev], [&] { errs[dev] = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes); });
+        return errs[dev];
+    }
+};
 
 // ---------------------------------------------------------------------------------------------
 // profiling classes (include/diffpir_engine.h)

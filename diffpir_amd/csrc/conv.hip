@@ -380,11 +380,8 @@ static Status launch_mode(hipStream_t s, ConvK k) {
     k.n_co_blocks = (k.Cout + BCO - 1) / BCO;
     size_t lds = (size_t)(TAPS * KC * BCO + 2 * KC * 8 * 4 + KC * k.chs) * sizeof(float);
     auto fn = conv_mfma_kernel<KS, KC, WAVES_CO, WCO, WPX, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     // split-K for launches that cannot fill 256 CUs x 2 workgroups (low-resolution layers): partial slabs +
     // an ordered reduce, so results stay bitwise reproducible
     const int chunks = (k.Cin + KC - 1) / KC;

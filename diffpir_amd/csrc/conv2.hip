@@ -334,6 +334,8 @@ static int ilog2c(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
 const float* conv_zero_page() {
     static std::map<int, float*> pages;        // one read-only zero page per device
+    static std::mutex mu;
+    std::lock_guard<std::mutex> lk(mu);
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     auto it = pages.find(dev);
@@ -352,11 +354,8 @@ static Status launch2(hipStream_t s, Conv2K k, size_t partial_cap) {
     constexpr int WCHUNK = KC * TAPS * 64;
     size_t lds = (size_t)(2 * WCHUNK + 2 * 4 * KC * 8 * 4 + 2 * KC * NP * 256) * sizeof(float);
     auto fn = conv2_mfma_kernel<KS, KC, MODE>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     const int chunks = (k.Cin + KC - 1) / KC;
     const int blocks = k.n_ptiles * k.n_co_blocks;
     int S = 1;

@@ -500,11 +500,8 @@ static Status launch6(hipStream_t s, Conv6K k, int blocks) {
     constexpr size_t LDS = (size_t)4 * NPIECE * 1024 + (size_t)4 * R * 2048;
     static_assert(2 * LDS <= 160 * 1024, "two workgroups per CU");
     auto fn = conv6_mfma_kernel<GEO, R, X1>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-        attr_set = true;
-    }
+    static LdsAttrOnce attr_set;
+    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), (int)LDS));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), LDS, s, k);
     return Status{};
 }

@@ -218,11 +218,8 @@ static Status launch_cols_mode(hipStream_t s, const FftPlan& ph, float2* buf, co
     if (ph.N != H) return invalid("fft cols: plan size mismatch");
     size_t lds = ((H >> 1) + (size_t)CW * (H + 1)) * sizeof(float2);
     auto fn = fft_cols_kernel<MODE>;
-    static bool attr = false;
-    if (!attr) {
-        DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr = true;
-    }
+    static LdsAttrOnce attr;
+    DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     hipLaunchKernelGGL(fn, dim3((unsigned)(P * (W / CW))), dim3(256), lds, s, buf, a, H, W, ph.logN, ph.tw);
     DPIR_HIP(hipGetLastError());
     return Status{};

@@ -289,8 +289,8 @@ static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, flo
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
     auto fn = rfft_rows_kernel<R, ROW_THREADS>;
-    static bool attr = false;
-    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static LdsAttrOnce attr;
+    DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw, fu);
     DPIR_HIP(hipGetLastError());
     return Status{};
@@ -309,8 +309,8 @@ static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float sc
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
     auto fn = irfft_rows_kernel<R, ROW_THREADS>;
-    static bool attr = false;
-    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static LdsAttrOnce attr;
+    DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
                        rows, tw, rn);
     DPIR_HIP(hipGetLastError());
@@ -330,8 +330,8 @@ static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P
     constexpr int COL_THREADS = ColCfg<R>::THREADS;
     constexpr int CS = COL_THREADS / R;
     auto fn = cfft_cols_kernel<R, MODE, COL_THREADS>;
-    static bool attr = false;
-    if (!attr) { DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr = true; }
+    static LdsAttrOnce attr;
+    DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), cols_lds<R>(), s, buf, a, WP, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
