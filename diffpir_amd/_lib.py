@@ -42,6 +42,10 @@ class LoopDesc(C.Structure):
                 ("noise_rp_dev", C.c_void_p)]
 
 
+class DpsCoef(C.Structure):
+    _fields_ = [("pc1", C.c_float), ("pc2", C.c_float), ("min_log", C.c_float), ("max_log", C.c_float)]
+
+
 class DegradeDesc(C.Structure):
     _fields_ = [("task", C.c_int32), ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("sf", C.c_int32),
                 ("kh", C.c_int32), ("kw", C.c_int32), ("noise_level_img", C.c_float), ("seed", C.c_uint64), ("image_offset", C.c_int64)]
@@ -68,6 +72,10 @@ SIGNATURES = {
     "dpir_unet_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_model_fn_xstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                        C.c_int, C.c_int, C.c_int]),
+    "dpir_enable_grad": (C.c_int, [C.c_void_p, C.c_int]),
+    "dpir_unet_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_run_dps_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.POINTER(DpsCoef), C.c_int, C.c_void_p, C.c_float,
+                                    C.c_void_p, C.c_void_p]),
     "dpir_unet_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dpir_prox_fft_precalc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.POINTER(C.c_void_p)]),

@@ -74,20 +74,34 @@ __global__ __launch_bounds__(256) void act_split_kernel(CatSrc src, const float4
     range_report(bad, range_ctr);
 }
 
-// plain-resolution fast path: 4 consecutive pixels per thread (float4 loads per channel, 64-byte stores per plane)
-__global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float4* prm, int C, int C8, int HW, _Float16* hi, _Float16* lo,
+// fast path: 4 consecutive OUTPUT pixels per thread (float4 loads per channel, 64-byte stores per plane).
+// UP = false: plain resolution.  UP = true: nearest x2 up-sampling (unet.py:107) -- the 4 output pixels of a row are 2 source pixels
+// (one float2 load per channel); W is the OUTPUT width (W % 4 == 0), HW the output plane.
+template <bool UP>
+__global__ __launch_bounds__(256) void act_split4_kernel(CatSrc src, const float4* prm, int C, int C8, int HW, int W, _Float16* hi, _Float16* lo,
                                                          unsigned long long* range_ctr) {
     const int p4 = blockIdx.x * 256 + threadIdx.x;          // group of 4 pixels
     const int n = blockIdx.y / C8, c8 = blockIdx.y - n * C8;
     const bool live = p4 * 4 < HW;
+    const int HWs = UP ? HW >> 2 : HW;                       // source plane
+    size_t soff = (size_t)p4 * 4;
+    if (UP) {
+        const int y = (p4 * 4) / W, x0 = p4 * 4 - y * W;
+        soff = (size_t)(y >> 1) * (W >> 1) + (x0 >> 1);
+    }
     float4 v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const int c = c8 * 8 + j;
         v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (c < C && live) {
-            const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HW : src.b + ((size_t)n * src.cb + (c - src.ca)) * HW;
-            v[j] = *reinterpret_cast<const float4*>(plane + (size_t)p4 * 4);
+            const float* plane = c < src.ca ? src.a + ((size_t)n * src.ca + c) * HWs : src.b + ((size_t)n * src.cb + (c - src.ca)) * HWs;
+            if (UP) {
+                const float2 s2 = *reinterpret_cast<const float2*>(plane + soff);
+                v[j] = make_float4(s2.x, s2.x, s2.y, s2.y);
+            } else {
+                v[j] = *reinterpret_cast<const float4*>(plane + soff);
+            }
         }
     }
     if (prm) {
@@ -356,7 +370,10 @@ Status launch_act_split(hipStream_t s, CatSrc src, const float4* prm, int mode, 
     _Float16* l = reinterpret_cast<_Float16*>(lo);
     if (mode == 0 && (H * W) % 4 == 0) {
         dim3 g4((unsigned)((H * W / 4 + 255) / 256), (unsigned)(B * C8));
-        hipLaunchKernelGGL(act_split4_kernel, g4, dim3(256), 0, s, src, prm, C, C8, H * W, h, l, range_ctr);
+        hipLaunchKernelGGL(act_split4_kernel<false>, g4, dim3(256), 0, s, src, prm, C, C8, H * W, W, h, l, range_ctr);
+    } else if (mode == 1 && W % 4 == 0 && H % 2 == 0) {
+        dim3 g4((unsigned)((H * W / 4 + 255) / 256), (unsigned)(B * C8));
+        hipLaunchKernelGGL(act_split4_kernel<true>, g4, dim3(256), 0, s, src, prm, C, C8, H * W, W, h, l, range_ctr);
     } else if (mode == 0) hipLaunchKernelGGL(act_split_kernel<0>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);
     else if (mode == 1) hipLaunchKernelGGL(act_split_kernel<1>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);
     else hipLaunchKernelGGL(act_split_kernel<2>, grid, dim3(256), 0, s, src, prm, C, C8, H, W, h, l, range_ctr);

@@ -2,6 +2,7 @@
 // restoration loop with hipGraph capture.  Each entry cites the reference interface it replaces in
 // the header; this file only validates, dispatches to the launchers and keeps the error string.
 #include "engine.h"
+#include "grad.h"
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
@@ -263,6 +264,30 @@ int dpir_unet_read_tap(dpir_engine* e, const char* layer, float* host_dst, size_
 
 double dpir_unet_flops(dpir_engine* e, int H, int W) { return e ? unet_flops(e->net, H, W) : 0.0; }
 double dpir_unet_flops_class(dpir_engine* e, int H, int W, int cls) { return e ? unet_flops(e->net, H, W, cls) : 0.0; }
+
+// ------------------------------------------------------------------------------------------ gradient mode (8f-4)
+int dpir_enable_grad(dpir_engine* e, int on) {
+    if (!e) return DPIR_ERR_INVALID;
+    if (e->net.loaded && (on != 0) != e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "dpir_enable_grad must be called before dpir_load_unet"});
+    e->grad_enabled = on != 0;
+    return DPIR_OK;
+}
+
+int dpir_unet_vjp(dpir_engine* e, const float* x, const int64_t* t_host, const int64_t* y_host, const float* gout, float* out, float* dx,
+                  int B, int H, int W) {
+    if (!e || !x || !t_host || !gout || !dx) return fail(e, invalid("dpir_unet_vjp: null argument"));
+    (void)hipSetDevice(e->device);
+    if (!e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "dpir_unet_vjp: gradient mode is off (dpir_enable_grad before dpir_load_unet)"});
+    int *t_dev = nullptr, *y_dev = nullptr;
+    range_clear(e);
+    API_TRY(e, upload_ints(e, "api#t", t_host, B, &t_dev));
+    API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
+    float* o6 = out;
+    if (!o6) API_TRY(e, e->ws.getT("api#out6", (size_t)B * e->net.desc.out_channels * H * W, &o6));
+    API_TRY(e, unet_forward(e, x, t_dev, y_dev, o6, B, H, W));
+    API_TRY(e, unet_backward(e, gout, dx));
+    return DPIR_OK;
+}
 
 // ------------------------------------------------------------------------------------------ FFT prox
 static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, ProxState* st) {
@@ -810,6 +835,85 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     {
         ProfScope ps(&e->prof, PC_ELEM);
         API_TRY(e, launch_finalize(e->stream, b.x, out_f32, out_u8, B, H * W));
+    }
+    return DPIR_OK;
+}
+
+// ------------------------------------------------------------------------------------------ DPS_y0 loop (8f-4)
+int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* steps, const dpir_dps_coef* coefs, int n_steps,
+                      const float* noise_ps_dev, float step_scale, float* out_f32, uint8_t* out_u8) {
+    if (!e || !dd || !steps || !coefs || n_steps <= 0) return fail(e, invalid("dpir_run_dps_loop: null argument"));
+    (void)hipSetDevice(e->device);
+    const dpir_loop_desc& d = *dd;
+    if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
+    if (!e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "DPS needs gradient mode: dpir_enable_grad before dpir_load_unet"});
+    if (d.task != DPIR_TASK_SR_BLUR && d.task != DPIR_TASK_SR_CUBIC)
+        return fail(e, Status{DPIR_ERR_UNSUPPORTED, "DPS_y0 is implemented for the super-resolution tasks (the reference's deblurring operator raises at "
+                                                    "main_ddpir.py:302 and its inpainting branch never defines xt)"});
+    if (d.B <= 0 || d.H <= 0 || d.W <= 0 || d.sf < 1 || d.H % d.sf || d.W % d.sf || !d.y_dev) return fail(e, invalid("dpir_run_dps_loop: bad shape"));
+    if ((e->net.desc.num_classes > 0) != (d.labels_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
+    const int B = d.B, H = d.H, W = d.W, sf = d.sf, h = H / sf, w = W / sf, oc = e->net.desc.out_channels;
+    const size_t total = (size_t)B * 3 * H * W, small = (size_t)B * 3 * h * w;
+    hipStream_t s = e->stream;
+    range_clear(e);
+    LoopBufs b{};
+    float *xprev = nullptr, *down = nullptr, *diff = nullptr, *gmid = nullptr, *gup = nullptr, *dout6 = nullptr, *direct = nullptr, *dxn = nullptr, *normv = nullptr;
+    unsigned char* inside = nullptr; double* part = nullptr;
+    API_TRY(e, e->ws.getT("loop#x", total, &b.x));
+    API_TRY(e, e->ws.getT("loop#x0", total, &b.x0));
+    API_TRY(e, e->ws.getT("loop#out6", (size_t)B * oc * H * W, &b.out6));
+    API_TRY(e, e->ws.getT("loop#n2", total, &b.n2));
+    API_TRY(e, e->ws.getT("loop#init", total, &b.init_src));
+    API_TRY(e, e->ws.getT("loop#t", (size_t)B, &b.t_dev));
+    API_TRY(e, e->ws.getT("dps#xprev", total, &xprev));
+    API_TRY(e, e->ws.getT("dps#down", small, &down));
+    API_TRY(e, e->ws.getT("dps#diff", small, &diff));
+    API_TRY(e, e->ws.getT("dps#gmid", (size_t)B * 3 * h * W, &gmid));
+    API_TRY(e, e->ws.getT("dps#gup", total, &gup));
+    API_TRY(e, e->ws.getT("dps#dout6", (size_t)B * oc * H * W, &dout6));
+    API_TRY(e, e->ws.getT("dps#direct", total, &direct));
+    API_TRY(e, e->ws.getT("dps#dxn", total, &dxn));
+    API_TRY(e, e->ws.getT("dps#inside", total, &inside));
+    API_TRY(e, e->ws.getT("dps#part", (size_t)256, &part));
+    API_TRY(e, e->ws.getT("dps#norm", (size_t)4, &normv));
+    API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
+    ResizerTab th, tw;
+    API_TRY(e, e->resizer(H, sf, &th));
+    API_TRY(e, e->resizer(W, sf, &tw));
+    // init (main_ddpir.py:293-315): bicubic up-sampling of y, forward noising to t_start
+    {
+        ProfScope ps(&e->prof, PC_ELEM);
+        API_TRY(e, launch_bicubic_up(s, d.y_dev, b.init_src, B * 3, h, w, sf));
+        const float* n0 = d.noise_init_dev;
+        if (!n0) { API_TRY(e, launch_randn(s, b.n2, d.seed, 0, d.image_offset, B, (size_t)3 * H * W)); n0 = b.n2; }
+        API_TRY(e, launch_init_x(s, b.init_src, nullptr, n0, d.sa_start, d.s1m_start, b.x, total));
+    }
+    for (int i = 0; i < n_steps; ++i) {
+        const dpir_step& st = steps[i];
+        if (st.last && d.skip_dead_final_eval) continue;
+        std::vector<int64_t> tv(B, st.t);
+        int* t_dev = nullptr;
+        API_TRY(e, upload_ints(e, "loop#tt", tv.data(), B, &t_dev));
+        API_TRY(e, unet_forward(e, b.x, t_dev, b.y_dev, b.out6, B, H, W));
+        if (st.last) continue;                                   // the final denoiser call is dead (main_ddpir.py:384, 470)
+        const float* nz = noise_ps_dev ? noise_ps_dev + (size_t)i * total : nullptr;
+        ProfScope ps(&e->prof, PC_ELEM);
+        if (!nz) { API_TRY(e, launch_randn(s, b.n2, d.seed, (uint64_t)4 * (i + 1), d.image_offset, B, (size_t)3 * H * W)); nz = b.n2; }
+        PSampleCoef cf{st.c1, st.c2, coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log, st.t != 0 ? 1.0f : 0.0f};
+        API_TRY(e, launch_psample(s, b.x, b.out6, oc, nz, cf, b.x0, xprev, inside, B, H * W));
+        // difference = (2y - 1) - Resizer(x0), norm over the whole batch (utils_model.py:391-392)
+        API_TRY(e, resize_down_impl(e, b.x0, 1.f, 0.f, down, sf, B, H, W));
+        API_TRY(e, launch_diff_norm(s, d.y_dev, 2.f, -1.f, down, diff, small, part, 256, normv));
+        // Resizer^T: the forward resamples dim 2 (H) first, then dim 3 (W) -> adjoint W first, then H
+        API_TRY(e, launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
+        API_TRY(e, launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
+        API_TRY(e, launch_dps_seed(s, gup, normv, inside, st.c1, st.c2, oc, dout6, direct, B, H * W));
+        API_TRY(e, unet_backward(e, dout6, dxn));
+        API_TRY(e, launch_dps_update(s, xprev, direct, dxn, step_scale, b.x, nullptr, total));
+    }
+    {
+        ProfScope ps(&e->prof, PC_ELEM);
+        API_TRY(e, launch_finalize(s, b.x, out_f32, out_u8, B, H * W));
     }
     return DPIR_OK;
 }

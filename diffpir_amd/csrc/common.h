@@ -198,7 +198,7 @@ struct GnStatSrc { const float2* slots = nullptr; int nslots = 0; const double2*
 // the device) is used for every image (film_stride = 0)
 Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
                      const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm,
-                     const StepDev* fstep = nullptr, int frows = 0);
+                     const StepDev* fstep = nullptr, int frows = 0, float2* stats_out = nullptr);
 // time embedding MLP: t_dev [B] int32 -> semb [B, ted] = silu(time_embed(timestep_embedding(t)) + label_emb[y])
 Status launch_time_embed(hipStream_t s, const int* t_dev, const int* y_dev, const float* freqs, const float* w0, const float* b0,
                          const float* w2, const float* b2, const float* label_emb, int B, int mc, float* tmp, float* semb);

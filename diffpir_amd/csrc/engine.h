@@ -27,7 +27,8 @@ struct Workspace {
 };
 
 struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3;
-               void* w16 = nullptr; float w16_scale = 1.f; };   // operand-split f16 copy (precision modes 1, 2): conv6 layout for 3x3, conv5 layout for 1x1
+               void* w16 = nullptr; float w16_scale = 1.f;      // operand-split f16 copy (precision modes 1, 2): conv6 layout for 3x3, conv5 layout for 1x1
+               float* wT = nullptr; int coutpT = 0; };          // grad mode: the dgrad operand [coutP16][taps flipped][cinP64] (unet_bwd.hip)
 struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 struct ResW {
     std::string name;
@@ -58,6 +59,19 @@ struct UNet {
 
 struct TapInfo { const float* p; size_t numel; };
 
+// What the last forward left behind for the input-gradient pass (grad mode only; unet_bwd.hip walks it in reverse)
+struct TapeRes { int idx; CatSrc in; int inH, inW, Ho, Wo; float* h1; float* sk; float* out; float4* prm1; float2* st1; float4* prm2; float2* st2; };
+struct TapeAttn { int idx; const float* in; int H, W; float* qkv; float* att; float* out; float4* prm; float2* st; };
+struct TapeNode { int kind; int idx; };      // 1: res[idx], 2: attn[idx]
+struct Tape {
+    bool valid = false;
+    int B = 0, H = 0, W = 0;
+    float* conv_in_out = nullptr;
+    std::vector<TapeNode> nodes; std::vector<TapeRes> res; std::vector<TapeAttn> attn;
+    const float* final_h = nullptr; float4* final_prm = nullptr; float2* final_st = nullptr;
+    void clear() { valid = false; nodes.clear(); res.clear(); attn.clear(); }
+};
+
 struct ProxState {   // dpir_prox
     int B = 0, H = 0, W = 0, sf = 1;
     float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
@@ -85,6 +99,8 @@ struct dpir_engine {
     std::vector<void*> user_allocs;
     bool collect_taps = true;
     int precision = 0;           // 0: exact fp32 MFMA kernels; 1: operand-split f16x3 MFMA (fp32-equivalent accuracy)
+    bool grad_enabled = false;   // dpir_enable_grad before dpir_load_unet: dgrad weight packs + a tape per forward (DPS modes, 8f-4)
+    dpir::Tape tape;
     // Captured restoration steps.  A graph depends only on what is baked into its kernel arguments: the shape / task /
     // mode fields below and the workspace generation; per-batch pointers, seed and image offset live in a device block
     // (dpir::LoopDev), so every batch of a test set replays the same graph.  Entries are compared field by field on a
@@ -120,5 +136,7 @@ void unet_free(dpir_engine* e);
 Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W,
                     const float* film_table = nullptr, const StepDev* film_step = nullptr);
 Status unet_film_table(dpir_engine* e, const int* t_dev, int n_steps, float* table);
+// vector-Jacobian product of the LAST forward (grad mode): gout [B, out_channels, H, W] -> dx [B, 3, H, W]
+Status unet_backward(dpir_engine* e, const float* gout, float* dx);
 double unet_flops(const UNet& net, int H, int W, int cls = -1);
 }  // namespace dpir

@@ -1,0 +1,34 @@
+// Declarations for grad.hip / unet_bwd.hip: the input-gradient path (DPS modes).
+#pragma once
+#include "common.h"
+
+namespace dpir {
+
+// GroupNorm (+FiLM) + SiLU backward for one normalisation site.  x: the (virtual concat) source at Hs x Ws; prm / stats: the
+// forward's per-(image, channel) {mean, a, b, act} table and per-(image, group) {mean, rstd}; dA: gradient w.r.t. the activated,
+// resampled convolution input [B, C, Ho, Wo] (mode as in act.hip); sums: scratch [B * 32] double2.
+// Output: gradient w.r.t. x, written (acc = 0) or accumulated into ga (channels < ca) and gb (the rest).
+struct GnBwdArgs {
+    CatSrc x; const float4* prm = nullptr; const float2* stats = nullptr;
+    const float* dA = nullptr; int mode = 0; int Hs = 0, Ws = 0;
+    double2* sums = nullptr;
+    float* ga = nullptr; float* gb = nullptr; int acc_a = 0, acc_b = 0;
+};
+Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B);
+Status launch_accum_adj(hipStream_t s, const float* src, int Cs, int c0, float* dst, int Cd, int mode, int B, int Hs, int Ws, bool acc);
+Status launch_attention_bwd(hipStream_t s, const float* qkv, const float* dAtt, float* dqkv, float* P, float* dP, int B, int C, int T);
+
+// p_sample coefficients of the current timestep (float64 tables of GaussianDiffusion cast to float32 as _extract_into_tensor does)
+struct PSampleCoef { float c1, c2, pc1, pc2, min_log, max_log, nonzero; };
+Status launch_psample(hipStream_t s, const float* x, const float* out6, int out_ch, const float* noise, const PSampleCoef& cf, float* x0,
+                      float* xprev, unsigned char* inside, int B, int HW);
+Status launch_diff_norm(hipStream_t s, const float* y, float ma, float mb, const float* down, float* diff, size_t total, double* part, int nparts,
+                        float* norm_out);
+Status launch_band_resample_T(hipStream_t s, const float* gout, const float* w, const int* idx, int taps, int P, int L_in, int L_out, int inner,
+                              float scale, float* gin);
+Status launch_dps_seed(hipStream_t s, const float* gup, const float* norm, const unsigned char* inside, float c1, float c2, int out_ch, float* dout6,
+                       float* direct, int B, int HW);
+Status launch_dps_update(hipStream_t s, const float* xprev, const float* direct, const float* dx_net, float step_scale, float* x, float* grad_out,
+                         size_t total);
+
+}  // namespace dpir

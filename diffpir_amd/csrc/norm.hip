@@ -73,7 +73,7 @@ Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part) 
 // fixed order (thread-strided, then the usual wave/LDS tree), and writes the per-channel affine parameters.
 __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
                                                      const float* film, int film_stride, int film_off, int C, float act, float4* prm,
-                                                     const StepDev* fstep, int frows) {
+                                                     const StepDev* fstep, int frows, float2* stats_out) {
     const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
     // hoisted FiLM (dpir_run_loop): the projections of ALL steps were evaluated before the loop; row = current step, shared by the batch
     if (film && fstep) film += (size_t)fstep->i * frows;
@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb,
         double var = ss / cnt - mean * mean;
         if (var < 0) var = 0;
         st_sh = make_float2((float)mean, (float)(1.0 / sqrt(var + 1e-5)));
+        if (stats_out) stats_out[blockIdx.x] = st_sh;          // {mean, rstd} per (image, group): the backward pass needs rstd alone
     }
     __syncthreads();
     const float2 st = st_sh;
@@ -125,10 +126,10 @@ __global__ __launch_bounds__(256) void gn_prm_kernel(GnStatSrc sa, GnStatSrc sb,
 
 Status launch_gn_prm(hipStream_t s, GnStatSrc sa, GnStatSrc sb, int HW, const float* gamma, const float* beta,
                      const float* film, int film_stride, int film_off, int B, int C, bool silu, float4* prm,
-                     const StepDev* fstep, int frows) {
+                     const StepDev* fstep, int frows, float2* stats_out) {
     if (C % 32 || sa.c + sb.c != C) return invalid("gn_prm: channel bookkeeping");
     hipLaunchKernelGGL(gn_prm_kernel, dim3(B * 32), dim3(256), 0, s, sa, sb, HW, gamma, beta, film, film_stride,
-                       film_off, C, silu ? 1.0f : 0.0f, prm, fstep, frows);
+                       film_off, C, silu ? 1.0f : 0.0f, prm, fstep, frows, stats_out);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -81,6 +81,18 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
     out->cin = cin; out->cout = cout; out->coutp = coutp; out->ks = ks;
     DPIR_TRY(upload(e, packed.data(), packed.size(), &out->w));
     DPIR_TRY(upload(e, b, cout, &out->bias));
+    if (e->grad_enabled) {
+        // dgrad operand: dx[ci, q] = sum_co sum_t w[co, ci, taps-1-t] dy[co, q + off(t)] -- the forward kernel on the transposed,
+        // spatially flipped weights, roles of Cin / Cout exchanged (same [CinP][taps][CoutP] packing)
+        const int cinT = round_up(cout, 16), coutT = round_up(cin, 64);
+        std::vector<float> pt((size_t)cinT * taps * coutT, 0.f);
+        for (int co = 0; co < cout; ++co)
+            for (int ci = 0; ci < cin; ++ci)
+                for (int t = 0; t < taps; ++t)
+                    pt[((size_t)co * taps + t) * coutT + ci] = w[((size_t)co * cin + ci) * taps + (taps - 1 - t)];
+        out->coutpT = coutT;
+        DPIR_TRY(upload(e, pt.data(), pt.size(), &out->wT));
+    }
     if (e->precision >= 1 && (ks == 3 || ks == 1)) {
         std::vector<uint16_t> w16;
         out->w16_scale = ks == 3 ? pack_weights_conv6(w, cout, cin, w16) : pack_weights_f16x3_1x1(w, cout, cin, w16);
@@ -283,6 +295,7 @@ struct Fwd {
     // low-resolution prologue (gn_act_small) finishes it, or resolve() does -- before anything else reads the tensor or
     // reuses the slab buffer.
     PendingConv pending;
+    bool grad = false;    // grad mode: classic (unfused) prologues, GroupNorm tables kept, tape recorded
     bool fuse_small;
     bool emit_skip;       // conv5 emits conv1's operand planes in ResBlocks with a 1x1 skip projection
 
@@ -300,7 +313,7 @@ struct Fwd {
     // GroupNorm (+FiLM) + SiLU + 3x3 convolution.  Low-resolution layers on the f16 path take the fused prologue; everything
     // else the separate statistics / gn_prm / act_split (or fp32 in-kernel prologue) route.
     Status gn_conv(const GnW& g, const std::string& tag, int film_off, const ConvW& cw, const Act& in, int mode,
-                   const float* res, int res_mode, float* out, int Ho, int Wo) {
+                   const float* res, int res_mode, float* out, int Ho, int Wo, float4** prm_out = nullptr, float2** stats_out = nullptr) {
         const int C = in.C();
         const bool f16path = cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo);
         if (fuse_small && f16path && C == g.c && C % 16 == 0 && gn_act_small_supported(C, in.H, in.W, mode)) {
@@ -330,7 +343,8 @@ struct Fwd {
         }
         DPIR_TRY(resolve());
         float4* prm = nullptr;
-        DPIR_TRY(gn(g, in, tag, film_off, true, &prm));
+        DPIR_TRY(gn(g, in, tag, film_off, true, &prm, stats_out));
+        if (prm_out) *prm_out = prm;
         return conv(cw, in, mode, prm, res, res_mode, out, Ho, Wo);
     }
 
@@ -402,8 +416,10 @@ struct Fwd {
         ProfScope ps(&e->prof, cw.ks == 3 ? PC_CONV3 : PC_CONV1);
         return launch_conv(s, a);
     }
-    Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out) {
+    Status gn(const GnW& g, const Act& in, const std::string& tag, int film_off, bool silu, float4** prm_out, float2** stats_out = nullptr) {
         float4* prm = nullptr;
+        float2* gst = nullptr;
+        if (grad) DPIR_TRY(ws.getT(tag + "#gst", (size_t)B * 32, &gst));
         if (is_pending(in.a) || is_pending(in.b)) DPIR_TRY(resolve());
         DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * g.c, &prm));
         GnStatSrc src[2];
@@ -421,8 +437,9 @@ struct Fwd {
             src[k].part = part;
         }
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_gn_prm(s, src[0], src[1], in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_stride, film_off < 0 ? 0 : film_off, B, g.c, silu, prm, fstep, film_rows));
+        DPIR_TRY(launch_gn_prm(s, src[0], src[1], in.H * in.W, g.gamma, g.beta, film_off >= 0 ? film : nullptr, film_stride, film_off < 0 ? 0 : film_off, B, g.c, silu, prm, fstep, film_rows, gst));
         *prm_out = prm;
+        if (stats_out) *stats_out = gst;
         return Status{};
     }
     void tap(const std::string& name, const float* p, size_t numel) {
@@ -472,21 +489,29 @@ struct Fwd {
             out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
             return Status{};
         }
-        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo));
+        TapeRes tr{};
+        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo, &tr.prm1, &tr.st1));
         tap(r.name + "#h1", h1, on);
         if (r.has_skip) {
             float* sk = nullptr;
             DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
             DPIR_TRY(conv(r.skip, in, 0, nullptr, nullptr, 0, sk, Ho, Wo));
             res = sk;
+            tr.sk = sk;
         } else {
             if (in.b) return invalid("resblock " + r.name + ": identity skip on a concatenated input");
             res = in.a; res_mode = r.mode;
         }
         float* o = nullptr;
         DPIR_TRY(ws.getT(r.name + "#out", on, &o));
-        DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, res, res_mode, o, Ho, Wo));
+        DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, res, res_mode, o, Ho, Wo, &tr.prm2, &tr.st2));
         tap(r.name, o, on);
+        if (grad) {
+            tr.idx = (int)(&r - e->net.res.data());
+            tr.in = CatSrc{in.a, in.ca, in.b, in.cb}; tr.inH = in.H; tr.inW = in.W; tr.Ho = Ho; tr.Wo = Wo; tr.h1 = h1; tr.out = o;
+            e->tape.nodes.push_back(TapeNode{1, (int)e->tape.res.size()});
+            e->tape.res.push_back(tr);
+        }
         out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
         return Status{};
     }
@@ -495,8 +520,9 @@ struct Fwd {
         if (in.b || in.ca != aw.c) return invalid("attention " + aw.name + ": bad input");
         int T = in.H * in.W;
         float4* prm = nullptr;
+        float2* gst = nullptr;
         DPIR_TRY(resolve());
-        DPIR_TRY(gn(aw.norm, in, aw.name + "#norm", -1, false, &prm));
+        DPIR_TRY(gn(aw.norm, in, aw.name + "#norm", -1, false, &prm, &gst));
         float *qkv = nullptr, *att = nullptr, *o = nullptr;
         DPIR_TRY(ws.getT(aw.name + "#qkv", (size_t)B * 3 * aw.c * T, &qkv));
         DPIR_TRY(ws.getT(aw.name + "#att", (size_t)B * aw.c * T, &att));
@@ -511,6 +537,10 @@ struct Fwd {
         tap(aw.name + "#qkv", qkv, (size_t)B * 3 * aw.c * T);
         tap(aw.name + "#att", att, (size_t)B * aw.c * T);
         tap(aw.name, o, (size_t)B * aw.c * T);
+        if (grad) {
+            e->tape.nodes.push_back(TapeNode{2, (int)e->tape.attn.size()});
+            e->tape.attn.push_back(TapeAttn{(int)(&aw - e->net.attn.data()), in.a, in.H, in.W, qkv, att, o, prm, gst});
+        }
         out->a = o; out->ca = aw.c; out->b = nullptr; out->cb = 0; out->H = in.H; out->W = in.W;
         return Status{};
     }
@@ -576,8 +606,10 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     {
         static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
         static const bool emit_env = !(getenv("DPIR_EMIT_SKIP") && atoi(getenv("DPIR_EMIT_SKIP")) == 0);
-        f.fuse_small = fuse_env;
-        f.emit_skip = emit_env;
+        f.grad = e->grad_enabled;
+        f.fuse_small = fuse_env && !f.grad;
+        f.emit_skip = emit_env && !f.grad;
+        if (f.grad) { e->tape.clear(); e->tape.B = B; e->tape.H = H; e->tape.W = W; }
     }
     if (e->collect_taps) e->taps.clear();
 
@@ -592,6 +624,7 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         f.tap("input_blocks.0.0", o, on);
         h.a = o; h.ca = net.conv_in.cout; h.H = H; h.W = W;
         hs.push_back(h);
+        if (f.grad) e->tape.conv_in_out = o;
     }
     for (size_t i = 1; i < net.in_blocks.size(); ++i) {
         Act o;
@@ -612,8 +645,10 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         DPIR_TRY(f.run_block(net, net.out_blocks[i], cat, &o));
         h = o;
     }
-    DPIR_TRY(f.gn_conv(net.out_gn, "out#gn", -1, net.out_conv, h, 0, nullptr, 0, out, H, W));
+    float4* fprm = nullptr; float2* fst = nullptr;
+    DPIR_TRY(f.gn_conv(net.out_gn, "out#gn", -1, net.out_conv, h, 0, nullptr, 0, out, H, W, &fprm, &fst));
     DPIR_TRY(f.resolve());
+    if (f.grad) { e->tape.final_h = h.a; e->tape.final_prm = fprm; e->tape.final_st = fst; e->tape.valid = true; }
     f.tap("out", out, (size_t)B * net.desc.out_channels * H * W);
     return Status{};
 }

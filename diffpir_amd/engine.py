@@ -131,6 +131,26 @@ class Engine:
 
     precision = "f32"
 
+    def enable_grad(self, on=True):
+        """Gradient mode (generate_mode 'DPS_y0'): before load_unet / load_state_dict."""
+        self._check(self.lib.dpir_enable_grad(self.h, 1 if on else 0))
+        self.grad = bool(on)
+
+    grad = False
+
+    def unet_vjp(self, x, t, gout, y=None, out=None, dx=None):
+        """(forward output, J(x)^T gout): the input-gradient of the UNet that torch.autograd.grad computes in the reference."""
+        B, _, H, W = x.shape
+        t = np.ascontiguousarray(t, dtype=np.int64)
+        yv = None if y is None else np.ascontiguousarray(y, dtype=np.int64)
+        if out is None:
+            out = self.empty((B, self.out_channels, H, W))
+        if dx is None:
+            dx = self.empty((B, 3, H, W))
+        self._check(self.lib.dpir_unet_vjp(self.h, _ptr(x), t.ctypes.data, None if yv is None else yv.ctypes.data, _ptr(gout),
+                                           _ptr(out), _ptr(dx), B, H, W))
+        return out, dx
+
     def load_unet(self, desc: "_lib.UNetDesc", state_dict: Dict[str, np.ndarray]):
         n = len(state_dict)
         arr = (_lib.Tensor * n)()

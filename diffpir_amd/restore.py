@@ -74,13 +74,19 @@ class LoopConfig:
         if self.generate_mode not in GENERATE_MODES or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
                 or self.iter_num_U != 1:
             raise NotImplementedError("only generate_mode in (DiffPIR, repaint, vanilla), model_output_type=pred_xstart, "
-                                      "sub_1_analytic=true, iter_num_U=1 are on the accelerated path (SURVEY.md 8f)")
-        if self.generate_mode != "DiffPIR" and self.task != "inpaint":
+                                      "sub_1_analytic=true, iter_num_U=1 are on the accelerated path (SURVEY.md 8f); DPS_y0 is the "
+                                      "gradient-based mode that is built (task sr)")
+        if self.generate_mode == "DPS_y0":
+            # main_ddpir.py:370-373, 434-438.  Runnable in the reference for task 'sr' only: the deblurring operator raises at :302
+            #  and the inpainting branch never defines xt.  DPS_yt / first-order (sub_1_analytic: false) are not built.
+            if self.task != "sr":
+                raise NotImplementedError("generate_mode DPS_y0 is implemented for task 'sr' (the only one the reference can run)")
+        elif self.generate_mode != "DiffPIR" and self.task != "inpaint":
             # main_ddpir.py:448: outside DiffPIR mode x is only re-noised for inpainting; other tasks would leave x untouched
             raise NotImplementedError("generate_mode repaint / vanilla are inpainting modes in the reference")
 
 
-GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2}
+GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2, "DPS_y0": 3}
 
 
 def t_start_of(cfg: LoopConfig, reduced) -> int:
@@ -138,6 +144,8 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     Returns a DeviceArray [B,3,H,W] = x_0 in [0,1] (un-clamped, main_ddpir.py:470), and the u8 NHWC
     array as well when return_u8."""
     cfg.check_supported()
+    if cfg.generate_mode == "DPS_y0":
+        return _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8)
     dt, steps, arr = _steps(cfg)
     keep = []
 
@@ -199,6 +207,54 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
         _cache["keep"] = keep
     else:
         engine.sync()
+    return (out_f32, out_u8) if return_u8 else out_f32
+
+
+def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8):
+    """generate_mode 'DPS_y0' (main_ddpir.py:370-373, 434-438): dpir_run_dps_loop.  Host noise order: init, then ONE p_sample draw per
+    step (there is no re-noising in this mode, main_ddpir.py:448)."""
+    from .schedule import DiffusionTables
+    if not engine.grad:
+        raise EngineError("generate_mode DPS_y0 needs Engine.enable_grad() before the model is loaded")
+    dt, steps, arr = _steps(cfg)
+    dtab = DiffusionTables.make(cfg.num_train_timesteps)
+    coefs = (_lib.DpsCoef * len(steps))()
+    for i, st in enumerate(steps):
+        coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log = [float(v) for v in dtab.dps_coef(st["t"])]
+    yd = engine.to_device(y, np.float32) if isinstance(y, np.ndarray) else y
+    B, _, h, w = yd.shape
+    H, W = h * cfg.sf, w * cfg.sf
+    d = _lib.LoopDesc()
+    d.task = cfg.engine_task()
+    d.B, d.H, d.W, d.sf = B, H, W, cfg.sf
+    t_start = t_start_of(cfg, dt.reduced)
+    d.sa_start, d.s1m_start = float(dt.sqrt_ac[t_start]), float(dt.sqrt_1m_ac[t_start])
+    d.y_dev = _ptr(yd)
+    lab = None
+    if labels is not None:
+        lab = np.ascontiguousarray(labels, dtype=np.int64)
+        d.labels_host = lab.ctypes.data
+    keep = [yd]
+    nps = None
+    if noise_source == "host":
+        if noise_fn is None:
+            raise EngineError("noise_source='host' needs noise_fn")
+        init = np.asarray(noise_fn((B, 3, H, W)), dtype=np.float32)
+        ps = np.stack([np.asarray(noise_fn((B, 3, H, W)), dtype=np.float32) for _ in steps])
+        di, nps = engine.to_device(init), engine.to_device(ps)
+        keep += [di, nps]
+        d.noise_init_dev = di.ptr
+    elif noise_source != "device":
+        raise ValueError("noise_source must be 'host' or 'device'")
+    d.seed, d.image_offset = seed, image_offset
+    d.skip_dead_final_eval = int(skip_dead_final_eval)
+    d.generate_mode = GENERATE_MODES["DPS_y0"]
+    if out_f32 is None:
+        out_f32 = engine.empty((B, 3, H, W))
+    if out_u8 is None and return_u8:
+        out_u8 = engine.empty((B, H, W, 3), np.uint8)
+    engine._check(engine.lib.dpir_run_dps_loop(engine.h, C.byref(d), arr, coefs, len(steps), _ptr(nps), 1.0, _ptr(out_f32), _ptr(out_u8)))
+    engine.sync()
     return (out_f32, out_u8) if return_u8 else out_f32
 
 

@@ -47,13 +47,28 @@ class DiffusionTables:
     """GaussianDiffusion.__init__ float64 tables (gaussian_diffusion.py:133-151), linear schedule :27-35."""
     sqrt_recip_ac: np.ndarray
     sqrt_recipm1_ac: np.ndarray
+    # posterior q(x_{t-1} | x_t, x_0) and the learned-range variance bounds (gaussian_diffusion.py:153-167, 268-276): p_sample of
+    # the DPS modes (model_out_type 'pred_x_prev_and_start')
+    posterior_mean_coef1: np.ndarray = None
+    posterior_mean_coef2: np.ndarray = None
+    posterior_log_variance_clipped: np.ndarray = None
+    log_betas: np.ndarray = None
 
     @staticmethod
     def make(T=1000) -> "DiffusionTables":
         scale = 1000 / T
         betas = np.linspace(scale * 0.0001, scale * 0.02, T, dtype=np.float64)
         ac = np.cumprod(1.0 - betas, axis=0)
-        return DiffusionTables(np.sqrt(1.0 / ac), np.sqrt(1.0 / ac - 1))
+        ac_prev = np.append(1.0, ac[:-1])
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        return DiffusionTables(np.sqrt(1.0 / ac), np.sqrt(1.0 / ac - 1),
+                               betas * np.sqrt(ac_prev) / (1.0 - ac), (1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac),
+                               np.log(np.append(post_var[1], post_var[1:])), np.log(betas))
+
+    def dps_coef(self, t: int):
+        """(posterior_mean_coef1, posterior_mean_coef2, min_log, max_log) at t as float32 (_extract_into_tensor(...).float())."""
+        return (np.float32(self.posterior_mean_coef1[t]), np.float32(self.posterior_mean_coef2[t]),
+                np.float32(self.posterior_log_variance_clipped[t]), np.float32(self.log_betas[t]))
 
     def c1c2(self, t: int):
         return np.float32(self.sqrt_recip_ac[t]), np.float32(self.sqrt_recipm1_ac[t])

@@ -214,6 +214,29 @@ typedef struct dpir_loop_desc {
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
                   float* out_f32_dev, uint8_t* out_u8_dev);
 
+/* ---- gradient-based sampling (generate_mode 'DPS_y0') ---------------------- */
+/* Replaces what torch.autograd does for the reference's DPS branch (main_ddpir.py:370-373, 434-438 with
+ * utils_model.grad_and_value, utils/utils_model.py:390-394).  Gradient mode must be switched on BEFORE dpir_load_unet: it builds
+ * the dgrad weight packs and makes every forward record what the backward needs (the fused elementwise prologues are off). */
+int dpir_enable_grad(dpir_engine* e, int on);
+/* Vector-Jacobian product of UNetModel.forward w.r.t. its input: runs the forward (out_dev [B,out_channels,H,W], may be NULL) and
+ * returns dx_dev [B,3,H,W] = J(x)^T gout_dev, gout_dev [B,out_channels,H,W].  The unit the parity tests compare with
+ * torch.autograd.grad on the reference network; per-layer gradients are readable as taps named "grad:<layer>". */
+int dpir_unet_vjp(dpir_engine* e, const float* x_dev, const int64_t* t_host, const int64_t* y_host, const float* gout_dev,
+                  float* out_dev, float* dx_dev, int B, int H, int W);
+/* Per-step p_sample coefficients (gaussian_diffusion.py:153-167, 268-276: float64 tables cast to float32 by
+ * _extract_into_tensor): posterior_mean_coef1/2[t], posterior_log_variance_clipped[t], log(betas[t]). */
+typedef struct dpir_dps_coef { float pc1, pc2, min_log, max_log; } dpir_dps_coef;
+/* generate_mode 'DPS_y0' for the super-resolution tasks (the only DPS variant the reference can run as shipped: its deblurring
+ * operator raises at main_ddpir.py:302 and the inpainting branch never defines xt).  Per step:
+ *   xt, x0 = p_sample(x)                       (model_fn 'pred_x_prev_and_start', utils_model.py:207-258)
+ *   norm   = || (2y - 1) - Resizer(x0) ||_2    over the whole batch          (grad_and_value)
+ *   x      = xt - step_scale * d norm / d x    (main_ddpir.py:437, step_scale = 1), no re-noising (:448)
+ * d / steps_host as in dpir_run_loop (task DPIR_TASK_SR_BLUR or _SR_CUBIC; k / mask / n1 / n2 unused); coefs_host [n_steps];
+ * noise_ps_dev: host-fed p_sample noise [n_steps, B,3,H,W] in step order or NULL -> device Philox (stream 4*(step+1)). */
+int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, const dpir_dps_coef* coefs_host, int n_steps,
+                      const float* noise_ps_dev, float step_scale, float* out_f32_dev, uint8_t* out_u8_dev);
+
 /* ---- multi-GPU: the one collective of the path ------------------------------ */
 /* One process and one engine per GPU; images are block-partitioned over ranks, no exchange inside the loop (the reference is
  * single-GPU: main_ddpir.py:135 sets world_size and never uses it).  After a batch, ONE all-gather of the uint8 results over

@@ -53,6 +53,13 @@ class DiffusionTables:
         ac = np.cumprod(1.0 - betas, axis=0)
         self.sqrt_recip_ac = np.sqrt(1.0 / ac)
         self.sqrt_recipm1_ac = np.sqrt(1.0 / ac - 1)
+        # posterior q(x_{t-1} | x_t, x_0) and the learned-range variance bounds (gaussian_diffusion.py:142-167, 268-276)
+        ac_prev = np.append(1.0, ac[:-1])
+        post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
+        self.posterior_log_variance_clipped = np.log(np.append(post_var[1], post_var[1:]))
+        self.posterior_mean_coef1 = betas * np.sqrt(ac_prev) / (1.0 - ac)
+        self.posterior_mean_coef2 = (1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac)
+        self.log_betas = np.log(betas)
 
 
 def find_nearest(array, value) -> int:
@@ -296,6 +303,55 @@ def tensor2uint_batch(x01):
     img = x01.float().clamp(0, 1).cpu().numpy()
     img = np.transpose(img, (0, 2, 3, 1))
     return np.uint8((img * 255.0).round())
+
+
+def p_sample_prev_and_start(sd, hp, x, t_step: int, dtab: DiffusionTables, noise, y_label=None):
+    """utils_model.model_fn(..., model_out_type='pred_x_prev_and_start') = GaussianDiffusion.p_sample with the LEARNED_RANGE
+    variance (gaussian_diffusion.py:232-326, 395-439): returns (sample, pred_xstart), differentiable w.r.t. x."""
+    vec_t = torch.tensor([t_step] * x.shape[0])
+    out = uo.unet_forward(sd, hp, x, vec_t, y_label)
+    eps, v = out[:, :3], out[:, 3:]
+    min_log = torch.tensor(dtab.posterior_log_variance_clipped[t_step]).float()
+    max_log = torch.tensor(dtab.log_betas[t_step]).float()
+    frac = (v + 1) / 2
+    log_var = frac * max_log + (1 - frac) * min_log
+    x0 = pred_xstart_from_eps(x, eps, t_step, dtab)
+    mean = torch.tensor(dtab.posterior_mean_coef1[t_step]).float() * x0 + torch.tensor(dtab.posterior_mean_coef2[t_step]).float() * x
+    nonzero = 0.0 if t_step == 0 else 1.0
+    return mean + nonzero * torch.exp(0.5 * log_var) * noise, x0
+
+
+def restore_dps_y0(sd, hp, cfg: LoopConfig, y, noise_fn: Callable, y_label=None, trace: Optional[list] = None):
+    """generate_mode 'DPS_y0' for task 'sr' (main_ddpir.py:370-373, 434-438 with utils_model.grad_and_value :390-394; the
+    deblurring variant cannot run in the reference as shipped, SURVEY Q1, and the inpainting branch never defines xt):
+        xt, x0 = p_sample(x);   norm = || (2y - 1) - Resizer(x0) ||_2 over the WHOLE batch;   x <- xt - d norm / d x
+    No re-noising (main_ddpir.py:448 is DiffPIR / inpainting only); the final step's denoiser call is dead.  RNG order: init,
+    then one p_sample draw per step."""
+    if cfg.task != "sr":
+        raise ValueError("DPS_y0 is runnable in the reference for task 'sr' only")
+    dt, steps = step_tables(cfg)
+    dtab = DiffusionTables(cfg.T)
+    y = y.float()
+    t_start = cfg.t_start(dt)
+    H, W = y.shape[2] * cfg.sf, y.shape[3] * cfg.sf
+    x = init_x(cfg, y, None, dt, noise_fn(torch.empty(y.shape[0], 3, H, W)), t_start)
+    for st in steps:
+        t_i = st["t_i"]
+        if t_i > t_start:
+            continue
+        x = x.detach().requires_grad_()
+        t_step = find_nearest(dt.reduced, st["curr_sigma"] * 255 / 255.0)
+        xt, x0 = p_sample_prev_and_start(sd, hp, x, t_step, dtab, noise_fn(x), y_label)
+        if trace is not None:
+            trace.append(("x0", t_i, x0.detach().clone()))
+        if not st["last"]:
+            difference = (2 * y - 1) - resizer_apply(x0, 1.0 / cfg.sf)
+            norm = torch.linalg.norm(difference)
+            norm_grad = torch.autograd.grad(outputs=norm, inputs=x)[0]
+            if trace is not None:
+                trace.append(("norm_grad", t_i, norm_grad.clone()))
+            x = (xt - norm_grad * 1.).detach()
+    return x.detach() / 2 + 0.5
 
 
 def psnr_batch(a, b, max_pixel=2.0, eps=1e-10):

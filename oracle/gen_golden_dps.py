@@ -1,0 +1,66 @@
+"""Golden vectors for the gradient-based mode from the LIVE reference:
+
+  * `post_*`       : GaussianDiffusion's posterior / learned-range tables (gaussian_diffusion.py:153-167) that p_sample reads;
+  * `vjp_tiny_*`, `vjp_ffhq64_*` : torch.autograd.grad of <UNetModel(x, t), g> w.r.t. x through the reference network (tiny topology at
+                     64x64, B = 2; FFHQ topology at 64x64, B = 1) -- what utils_model.grad_and_value differentiates through;
+  * `dps_*`        : a whole generate_mode 'DPS_y0' restoration (task sr x4, tiny topology, B = 2, 5 NFE) through the reference's own
+                     model_fn('pred_x_prev_and_start') / Resizer / grad_and_value (main_ddpir.py:370-373, 434-438), with the first
+                     step's norm_grad.  Parameters keep requires_grad as main_ddpir.py:236-239 leaves them for DPS_y0.
+
+TEST INFRASTRUCTURE ONLY; build container only (needs /root/reference).
+    python -m oracle.gen_golden_dps   ->  tests/golden/dps.npz
+"""
+import os
+import numpy as np
+import torch
+
+from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def seeded_noise_fn(seed):
+    g = torch.Generator().manual_seed(seed)
+    return lambda like: torch.randn(like.shape, generator=g, dtype=torch.float32)
+
+
+def vjp_case(out, tag, hp, B, size, seed):
+    sd = uo.synth_state_dict(hp, 0)
+    model, diffusion = live_reference.build_unet(hp, sd, frozen=False)
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 3, size, size), generator=g)
+    gout = torch.randn((B, 6, size, size), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    xa = x.clone().requires_grad_()
+    dx = torch.autograd.grad((model(xa, t) * gout).sum(), xa)[0]
+    xb = x.clone().requires_grad_()
+    dxo = torch.autograd.grad((uo.unet_forward(sd, hp, xb, t) * gout).sum(), xb)[0]
+    out.update({f"{tag}_seed": np.array(seed), f"{tag}_t": t.numpy(), f"{tag}_dx": dx.numpy()})
+    print(tag, "input gradient: live reference vs oracle max abs diff", float((dx - dxo).abs().max()), "range", float(dx.abs().max()), flush=True)
+    return model, diffusion, sd
+
+
+def main():
+    from diffpir_amd import synth
+    torch.set_num_threads(8)
+    out = {}
+    hp = uo.tiny_hp()
+    model, diffusion, sd = vjp_case(out, "vjp_tiny", hp, 2, 64, 41)
+    out.update(post_coef1=diffusion.posterior_mean_coef1, post_coef2=diffusion.posterior_mean_coef2,
+               post_logvar=diffusion.posterior_log_variance_clipped, log_betas=np.log(diffusion.betas))
+    case = synth.make_case("sr", 2, 64, 64, seed=3, sf=4)
+    cfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+    y, k = torch.from_numpy(case["y"]), torch.from_numpy(case["k"])
+    tr, tro = [], []
+    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(81), trace=tr).numpy()
+    ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(81), trace=tro).numpy()
+    ng = [v for n, _, v in tr if n == "norm_grad"][0].numpy()
+    out.update(dps_y=case["y"], dps_gt=case["gt"], dps_out=ref, dps_seed=np.array(81), dps_nfe=np.array(5), dps_norm_grad0=ng)
+    print("DPS_y0 5-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "| first norm_grad max", float(np.abs(ng).max()), flush=True)
+    vjp_case(out, "vjp_ffhq64", uo.ffhq_hp(), 1, 64, 42)
+    np.savez_compressed(os.path.join(OUT, "dps.npz"), **out)
+    print("wrote dps.npz")
+
+
+if __name__ == "__main__":
+    main()

@@ -29,8 +29,10 @@ def patched_randn_like(noise_fn):
         torch.randn_like = orig
 
 
-def build_unet(hp, sd):
-    """Instantiate the reference UNetModel + diffusion for oracle.unet_oracle.UNetHP `hp`."""
+def build_unet(hp, sd, frozen=True):
+    """Instantiate the reference UNetModel + diffusion for oracle.unet_oracle.UNetHP `hp`.  frozen=False mirrors
+    main_ddpir.py:236-239 for generate_mode DPS_y0: the parameters keep requires_grad (AttentionBlock's CheckpointFunction
+    differentiates w.r.t. them and fails otherwise)."""
     ns = ref_import.load()
     model = ns.script_util.create_model(
         image_size=hp.image_size, num_channels=hp.model_channels, num_res_blocks=hp.num_res_blocks,
@@ -44,14 +46,16 @@ def build_unet(hp, sd):
         model.num_classes = hp.num_classes
     model.load_state_dict(sd)
     model.eval()
-    for _, v in model.named_parameters():
-        v.requires_grad = False
+    if frozen:
+        for _, v in model.named_parameters():
+            v.requires_grad = False
     diffusion = ns.script_util.create_gaussian_diffusion(steps=1000, learn_sigma=hp.learn_sigma)
     return model, diffusion
 
 
 def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_label=None, trace=None):
-    """main_ddpir.py:259-470 for generate_mode DiffPIR / repaint / vanilla, model_output_type='pred_xstart'."""
+    """main_ddpir.py:259-470 for generate_mode DiffPIR / repaint / vanilla / DPS_y0 (the latter: task 'sr'; call WITHOUT
+    torch.no_grad), model_output_type='pred_xstart'."""
     ns = ref_import.load()
     utils_model, sr, Resizer = ns.utils_model, ns.utils_sisr, ns.utils_resizer.Resizer
     T = cfg.T
@@ -108,12 +112,25 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
             if cfg.task == "inpaint" and gen_mode == 'repaint':            # main_ddpir.py:355-358
                 x = (sqrt_alphas_cumprod[t_i] * (2 * y - 1) + sqrt_1m_alphas_cumprod[t_i] * torch.randn_like(x)) * mask \
                     + (1 - mask) * x
-            x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_xstart',
-                                      model_diffusion=model, diffusion=diffusion, ddim_sample=False,
-                                      alphas_cumprod=alphas_cumprod, **model_kwargs)
+            if 'DPS' in gen_mode:                                          # main_ddpir.py:370-373
+                x = x.requires_grad_()
+                xt, x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_x_prev_and_start',
+                                              model_diffusion=model, diffusion=diffusion, ddim_sample=False,
+                                              alphas_cumprod=alphas_cumprod, **model_kwargs)
+            else:
+                x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_xstart',
+                                          model_diffusion=model, diffusion=diffusion, ddim_sample=False,
+                                          alphas_cumprod=alphas_cumprod, **model_kwargs)
             if trace is not None:
-                trace.append(("x0", int(t_i), x0.clone()))
-            if seq[i] != seq[-1]:
+                trace.append(("x0", int(t_i), x0.detach().clone()))
+            if seq[i] != seq[-1] and gen_mode == 'DPS_y0':                 # main_ddpir.py:433-438
+                measurement = y if cfg.task == "deblur" else 2 * y - 1
+                norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=x, x_hat=x0, measurement=measurement)
+                if trace is not None:
+                    trace.append(("norm_grad", int(t_i), norm_grad.clone()))
+                x = xt - norm_grad * 1.
+                x = x.detach_()
+            elif seq[i] != seq[-1]:
                 tau = rhos[t_i].float().repeat(1, 1, 1, 1)
                 if gen_mode != 'DiffPIR':
                     pass                                                   # main_ddpir.py:385: step 2 is DiffPIR-only
@@ -130,6 +147,8 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
                         x0 = x0 / 2 + 0.5
                         x0 = x0 + cfg.gamma * up_sample((y - degrade_op(x0))) / (1 + rhos[t_i])
                         x0 = x0 * 2 - 1
+                if not (cfg.task == "inpaint" or gen_mode == 'DiffPIR'):   # main_ddpir.py:448: no re-noising otherwise
+                    continue
                 t_im1 = utils_model.find_nearest(reduced_alpha_cumprod, sigmas[seq[i + 1]].cpu().numpy())
                 eps = (x - sqrt_alphas_cumprod[t_i] * x0) / sqrt_1m_alphas_cumprod[t_i]
                 eta_sigma = cfg.eta * sqrt_1m_alphas_cumprod[t_im1] / sqrt_1m_alphas_cumprod[t_i] * torch.sqrt(betas[t_i])
@@ -137,5 +156,5 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
                         + eta_sigma * torch.randn_like(x)) + np.sqrt(cfg.zeta) * sqrt_1m_alphas_cumprod[t_im1] * torch.randn_like(x)
                 if trace is not None:
                     trace.append(("x", int(t_im1), x.clone()))
-            x_0 = (x / 2 + 0.5)
+        x_0 = (x.detach() / 2 + 0.5)
     return x_0

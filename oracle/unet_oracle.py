@@ -267,11 +267,16 @@ def _run_layers(sd, prefix, blk, h, emb, hp, taps):
     return h
 
 
-@torch.no_grad()
 def unet_forward(sd, hp: UNetHP, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
                  taps: Optional[dict] = None) -> torch.Tensor:
     """unet.py:634-663.  x [B,3,H,W] fp32, t [B] int64 -> [B,out_channels,H,W].
-    `taps`, if given, collects every layer's output keyed by its state-dict prefix."""
+    `taps`, if given, collects every layer's output keyed by its state-dict prefix.
+    Runs without autograd unless x requires grad (the DPS modes differentiate through the network, main_ddpir.py:370-373)."""
+    with torch.set_grad_enabled(bool(x.requires_grad)):
+        return _unet_forward(sd, hp, x, t, y, taps)
+
+
+def _unet_forward(sd, hp, x, t, y, taps):
     assert (y is not None) == hp.class_cond
     inp, mid, out = build_plan(hp)
     emb = timestep_embedding(t, hp.model_channels)

@@ -1,0 +1,123 @@
+"""-m gpu: the gradient-based mode.  The engine's UNet input-gradient (dgrad on the forward MFMA kernels + GroupNorm /
+SiLU / attention backward, csrc/unet_bwd.hip, csrc/grad.hip) against torch.autograd through the LIVE reference network
+(tests/golden/dps.npz) and, layer by layer, against autograd through the oracle; then generate_mode 'DPS_y0' as a whole loop against
+the reference's own model_fn('pred_x_prev_and_start') / Resizer / grad_and_value run."""
+import numpy as np
+import pytest
+import torch
+
+import diffpir_amd
+from diffpir_amd import restore
+from oracle import unet_oracle as uo, diffpir_oracle as do
+from tests.gpu_common import make_model, seeded_noise_fn_np, rel_err
+
+pytestmark = pytest.mark.gpu
+TOL_GRAD = 1e-4
+
+
+def _engine(hp, precision):
+    e = diffpir_amd.Engine(0)
+    e.set_precision(precision)
+    e.enable_grad()
+    model, sd = make_model(e, hp)
+    return e, sd
+
+
+def _inputs(seed, B, size):
+    gen = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 3, size, size), generator=gen)
+    gout = torch.randn((B, 6, size, size), generator=gen)
+    return x, gout
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_unet_input_gradient_tiny_layer_by_layer(golden, precision):
+    """J(x)^T g on the tiny topology (attention at 16^2 and 32^2, up / down-sampling ResBlocks, 1x1 skips, concat inputs) against the
+    live-reference fixture, and the gradient that reaches every block output against autograd through the oracle."""
+    g = golden("dps")
+    hp = uo.tiny_hp()
+    e, sd = _engine(hp, precision)
+    try:
+        x, gout = _inputs(int(g["vjp_tiny_seed"]), 2, 64)
+        t = g["vjp_tiny_t"]
+        out, dx = e.unet_vjp(e.to_device(x.numpy()), t, e.to_device(gout.numpy()))
+        taps = {}
+        xr = x.clone().requires_grad_()
+        o = uo.unet_forward(sd, hp, xr, torch.from_numpy(t), taps=taps)
+        for v in taps.values():
+            if v.requires_grad:
+                v.retain_grad()
+        (o * gout).sum().backward()
+        fwd = rel_err(out.numpy(), o.detach().numpy())
+        worst = ("", 0.0)
+        for name, tv in taps.items():
+            if name == "emb" or tv.grad is None:
+                continue
+            try:
+                got = e.read_tap("grad:" + name).reshape(tv.shape)
+            except diffpir_amd.EngineError:
+                continue
+            err = rel_err(got, tv.grad.numpy())
+            print(f"  grad {name:28s} rel err {err:.3e}")
+            if err > worst[1]:
+                worst = (name, err)
+        err = rel_err(dx.numpy(), g["vjp_tiny_dx"])
+        print(f"tiny UNet input gradient [{precision}]: rel err vs LIVE reference autograd {err:.3e}; worst layer gradient {worst[0]} {worst[1]:.3e}; "
+              f"forward rel err {fwd:.3e}")
+        assert fwd < 2e-5 and worst[1] < TOL_GRAD and err < TOL_GRAD
+    finally:
+        e.close()
+
+
+def test_unet_input_gradient_ffhq_topology_64(golden):
+    g = golden("dps")
+    hp = uo.ffhq_hp()
+    e, sd = _engine(hp, "f16x3")
+    try:
+        x, gout = _inputs(int(g["vjp_ffhq64_seed"]), 1, 64)
+        _, dx = e.unet_vjp(e.to_device(x.numpy()), g["vjp_ffhq64_t"], e.to_device(gout.numpy()))
+        err = rel_err(dx.numpy(), g["vjp_ffhq64_dx"])
+        print(f"FFHQ topology @64^2 input gradient [f16x3 forward]: rel err vs LIVE reference autograd {err:.3e}")
+        assert err < TOL_GRAD
+    finally:
+        e.close()
+
+
+def test_gradient_mode_must_be_enabled_before_load():
+    e = diffpir_amd.Engine(0)
+    try:
+        make_model(e, uo.tiny_hp())
+        with pytest.raises(diffpir_amd.EngineError):
+            e.enable_grad()
+        x, gout = _inputs(1, 1, 64)
+        with pytest.raises(diffpir_amd.EngineError, match="gradient mode"):
+            e.unet_vjp(e.to_device(x.numpy()), np.array([5]), e.to_device(gout.numpy()))
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_dps_y0_loop_matches_live_reference_fixture(golden, precision):
+    """generate_mode 'DPS_y0', task sr x4, 5 NFE, B = 2: p_sample with the learned-range variance, the batch-wide residual norm,
+    Resizer^T, the clamp mask, the UNet backward and x <- xt - norm_grad, against the reference's own run."""
+    g = golden("dps")
+    hp = uo.tiny_hp()
+    e, sd = _engine(hp, precision)
+    try:
+        cfg = restore.LoopConfig(task="sr", iter_num=int(g["dps_nfe"]), lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+        out = restore.restore_batch(e, cfg, g["dps_y"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["dps_seed"]))).numpy()
+        err = float(np.abs(out - g["dps_out"]).max())
+        gt = g["dps_gt"] * 2 - 1
+        gap = abs(restore.psnr_batch(out * 2 - 1, gt) - restore.psnr_batch(g["dps_out"] * 2 - 1, gt))
+        print(f"DPS_y0 5-NFE [{precision}] vs LIVE reference: max|diff| {err:.3e} (output range {np.abs(g['dps_out']).max():.2f}), |dPSNR| {gap:.2e} dB")
+        assert gap <= 1e-3 and err < 2e-4
+        dev = restore.restore_batch(e, cfg, g["dps_y"], noise_source="device", seed=3).numpy()      # Philox path runs and is finite
+        assert np.isfinite(dev).all()
+    finally:
+        e.close()
+
+
+def test_dps_rejects_tasks_the_reference_cannot_run():
+    cfg = restore.LoopConfig(task="deblur", iter_num=4, generate_mode="DPS_y0")
+    with pytest.raises(NotImplementedError):
+        cfg.check_supported()

@@ -249,3 +249,32 @@ def test_degradation_and_metrics_oracle_matches_live_reference(golden):
     np.testing.assert_array_equal(p, g["psnr"])
     np.testing.assert_array_equal(py, g["psnr_y"])
     assert abs(float(np.mean(p)) - float(g["psnr_batch"])) < 1e-5
+
+
+def test_dps_tables_vjp_and_loop_match_live_reference(golden):
+    """the posterior tables p_sample reads, the UNet input-gradient (torch.autograd through the restatement vs through the
+    reference network) and a whole generate_mode 'DPS_y0' restoration (oracle/gen_golden_dps.py)."""
+    from diffpir_amd import schedule, synth
+    g = golden("dps")
+    # The live tables come from SpacedDiffusion, which re-derives betas as 1 - acp[i] / acp[i-1] (respace.py:78-84): 4e-13 relative
+    # from the linear schedule in float64, identical after the .float() of _extract_into_tensor -- which is what p_sample consumes.
+    f32 = lambda a: np.asarray(a).astype(np.float32)
+    for tab in (do.DiffusionTables(1000), schedule.DiffusionTables.make(1000)):
+        np.testing.assert_array_equal(f32(tab.posterior_mean_coef1), f32(g["post_coef1"]))
+        np.testing.assert_array_equal(f32(tab.posterior_mean_coef2), f32(g["post_coef2"]))
+        np.testing.assert_array_equal(f32(tab.posterior_log_variance_clipped), f32(g["post_logvar"]))
+        np.testing.assert_array_equal(f32(tab.log_betas), f32(g["log_betas"]))
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    gen = torch.Generator().manual_seed(int(g["vjp_tiny_seed"]))
+    x = torch.randn((2, 3, 64, 64), generator=gen)
+    gout = torch.randn((2, 6, 64, 64), generator=gen)
+    xr = x.clone().requires_grad_()
+    dx = torch.autograd.grad((uo.unet_forward(sd, hp, xr, torch.from_numpy(g["vjp_tiny_t"])) * gout).sum(), xr)[0]
+    np.testing.assert_allclose(dx.numpy(), g["vjp_tiny_dx"], rtol=0, atol=1e-6)
+    cfg = do.LoopConfig("sr", int(g["dps_nfe"]), 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+    tr = []
+    out = do.restore_dps_y0(sd, hp, cfg, torch.from_numpy(g["dps_y"]), noise_fn=seeded_noise_fn(int(g["dps_seed"])), trace=tr)
+    np.testing.assert_allclose(out.numpy(), g["dps_out"], rtol=0, atol=2e-5)
+    ng = [v for n, _, v in tr if n == "norm_grad"][0]
+    np.testing.assert_allclose(ng.numpy(), g["dps_norm_grad0"], rtol=0, atol=1e-6)
