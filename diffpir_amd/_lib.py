@@ -38,7 +38,7 @@ class LoopDesc(C.Structure):
                 ("y_dev", C.c_void_p), ("k_dev", C.c_void_p), ("mask_dev", C.c_void_p), ("labels_host", C.c_void_p),
                 ("noise_init_dev", C.c_void_p), ("noise_n1_dev", C.c_void_p), ("noise_n2_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("image_offset", C.c_int64), ("use_graph", C.c_int32),
-                ("skip_dead_final_eval", C.c_int32), ("generate_mode", C.c_int32), ("reserved0", C.c_int32),
+                ("skip_dead_final_eval", C.c_int32), ("generate_mode", C.c_int32), ("first_order", C.c_int32),
                 ("noise_rp_dev", C.c_void_p)]
 
 
@@ -74,8 +74,8 @@ SIGNATURES = {
                                        C.c_int, C.c_int, C.c_int]),
     "dpir_enable_grad": (C.c_int, [C.c_void_p, C.c_int]),
     "dpir_unet_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
-    "dpir_run_dps_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.POINTER(DpsCoef), C.c_int, C.c_void_p, C.c_float,
-                                    C.c_void_p, C.c_void_p]),
+    "dpir_run_dps_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.POINTER(DpsCoef), C.c_int, C.c_int, C.c_float,
+                                    C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
     "dpir_unet_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dpir_prox_fft_precalc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.POINTER(C.c_void_p)]),

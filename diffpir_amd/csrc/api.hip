@@ -509,6 +509,32 @@ int dpir_bicubic_up(dpir_engine* e, const float* y, float* out, int sf, int B, i
 }
 
 // ------------------------------------------------------------------------------------------ loop arithmetic
+// First-order data step of the DiffPIR loop (sub_1_analytic: false, main_ddpir.py:420-430; task sr):
+//   x0 <- x0 - d|| (2y - 1) - Resizer(x0) || / dx0 * ||.|| / rho       -- the gradient needs no network backward
+static Status prox_first_order_impl(dpir_engine* e, float* x0, const float* y, float rho, int sf, int B, int H, int W,
+                                    const StepDev* sp = nullptr, const LoopDev* lp = nullptr) {
+    const int h = H / sf, w = W / sf;
+    const size_t total = (size_t)B * 3 * H * W, small = (size_t)B * 3 * h * w;
+    float *down = nullptr, *diff = nullptr, *gmid = nullptr, *gup = nullptr, *normv = nullptr; double* part = nullptr;
+    DPIR_TRY(e->ws.getT("fo#down", small, &down));
+    DPIR_TRY(e->ws.getT("fo#diff", small, &diff));
+    DPIR_TRY(e->ws.getT("fo#gmid", (size_t)B * 3 * h * W, &gmid));
+    DPIR_TRY(e->ws.getT("fo#gup", total, &gup));
+    DPIR_TRY(e->ws.getT("fo#part", (size_t)256, &part));
+    DPIR_TRY(e->ws.getT("fo#norm", (size_t)4, &normv));
+    ResizerTab th, tw;
+    DPIR_TRY(e->resizer(H, sf, &th));
+    DPIR_TRY(e->resizer(W, sf, &tw));
+    DPIR_TRY(resize_down_impl(e, x0, 1.f, 0.f, down, sf, B, H, W));
+    ProfScope ps(&e->prof, PC_ELEM);
+    hipStream_t s = e->stream;
+    DPIR_TRY(launch_diff_norm(s, y, 2.f, -1.f, down, diff, small, part, 256, normv, 1.f, 0.f, nullptr, lp));
+    DPIR_TRY(launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
+    DPIR_TRY(launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
+    DPIR_TRY(launch_grad_step(s, x0, gup, normv, 1.f, rho, 1.f, x0, total, sp));
+    return Status{};
+}
+
 static RenoiseCoef coef_of(const dpir_step& s) { return RenoiseCoef{s.sa_t, s.s1m_t, s.sa_p, s.k1, s.q, s.es, s.k2}; }
 
 int dpir_renoise(dpir_engine* e, float* x, const float* x0, const dpir_step* s, const float* n1, const float* n2, int B, int H, int W) {
@@ -644,7 +670,7 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
     DPIR_TRY(unet_forward(e, b.x, b.t_dev, b.y_dev, b.out6, B, H, W, b.film, b.film ? b.cur : nullptr));
     // FFT data step on the half-spectrum path, fused into three launches: eps -> clamped x0 in the row-FFT prologue, spectral
     // solve between the column FFTs, re-noise (+ Philox) in the inverse row-FFT epilogue.  x0 is never materialised.
-    if (!last && d.generate_mode == 0 && (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && prox->half && d.guidance == 1.0f) {
+    if (!last && d.generate_mode == 0 && !d.first_order && (d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR) && prox->half && d.guidance == 1.0f) {
         if (with_n1 && d.noise_n1_dev && !d.noise_n2_dev) return invalid("host n1 noise requires host n2 noise");
         const float2* tw = nullptr;
         DPIR_TRY(e->fft2_table(prox->W, &tw));
@@ -666,6 +692,8 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
     if (last) return Status{};
     if (d.generate_mode != 0) {
         // repaint / vanilla: no data-fidelity step (main_ddpir.py:385 is DiffPIR only)
+    } else if (d.first_order) {
+        DPIR_TRY(prox_first_order_impl(e, b.x0, d.y_dev, 0.f, d.sf, B, H, W, b.cur, b.lp));
     } else if (d.task == DPIR_TASK_INPAINT) {
         ProfScope ps(&e->prof, PC_ELEM);
         DPIR_TRY(launch_prox_mask(s, b.x0, d.y_dev, d.mask_dev, 0.f, d.guidance, total, b.cur, b.lp));
@@ -727,6 +755,9 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     if (d.generate_mode != 0 && d.task != DPIR_TASK_INPAINT)
         return fail(e, invalid("dpir_run_loop: repaint / vanilla are inpainting modes (main_ddpir.py:448 re-noises only for inpainting or DiffPIR)"));
     if ((e->net.desc.num_classes > 0) != (d.labels_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
+    if (d.first_order && (d.generate_mode != 0 || (d.task != DPIR_TASK_SR_BLUR && d.task != DPIR_TASK_SR_CUBIC)))
+        return fail(e, Status{DPIR_ERR_UNSUPPORTED, "the first-order data step (sub_1_analytic: false) is implemented for the DiffPIR mode of the "
+                                                    "super-resolution tasks (the reference's deblurring operator raises at main_ddpir.py:302)"});
     const int B = d.B, H = d.H, W = d.W;
     const size_t total = (size_t)B * 3 * H * W;
     range_clear(e);
@@ -795,7 +826,7 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
             auto make_key = [&]() {
                 dpir_engine::GraphKey k{};
                 k.task = d.task; k.B = B; k.H = H; k.W = W; k.sf = d.sf; k.in_iter = d.in_iter; k.generate_mode = d.generate_mode;
-                k.kind = (last ? 1 : 0) | (with_n1 ? 2 : 0);
+                k.kind = (last ? 1 : 0) | (with_n1 ? 2 : 0) | (d.first_order ? 4 : 0);
                 k.host_n1 = d.noise_n1_dev != nullptr; k.host_n2 = d.noise_n2_dev != nullptr; k.host_rp = d.noise_rp_dev != nullptr;
                 k.has_labels = d.labels_host != nullptr;
                 k.gamma = d.gamma; k.guidance = d.guidance; k.ws_generation = e->ws.generation;
@@ -841,12 +872,14 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
 
 // ------------------------------------------------------------------------------------------ DPS_y0 loop (8f-4)
 int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* steps, const dpir_dps_coef* coefs, int n_steps,
-                      const float* noise_ps_dev, float step_scale, float* out_f32, uint8_t* out_u8) {
+                      int variant, float lambda_, const float* noise_ps_dev, const float* noise_yt_dev, float step_scale, float* out_f32,
+                      uint8_t* out_u8) {
     if (!e || !dd || !steps || !coefs || n_steps <= 0) return fail(e, invalid("dpir_run_dps_loop: null argument"));
+    if (variant != 0 && variant != 1) return fail(e, invalid("dpir_run_dps_loop: variant must be 0 (DPS_y0) or 1 (DPS_yt)"));
     (void)hipSetDevice(e->device);
     const dpir_loop_desc& d = *dd;
     if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
-    if (!e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "DPS needs gradient mode: dpir_enable_grad before dpir_load_unet"});
+    if (variant == 0 && !e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "DPS_y0 needs gradient mode: dpir_enable_grad before dpir_load_unet"});
     if (d.task != DPIR_TASK_SR_BLUR && d.task != DPIR_TASK_SR_CUBIC)
         return fail(e, Status{DPIR_ERR_UNSUPPORTED, "DPS_y0 is implemented for the super-resolution tasks (the reference's deblurring operator raises at "
                                                     "main_ddpir.py:302 and its inpainting branch never defines xt)"});
@@ -901,6 +934,21 @@ int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step*
         if (!nz) { API_TRY(e, launch_randn(s, b.n2, d.seed, (uint64_t)4 * (i + 1), d.image_offset, B, (size_t)3 * H * W)); nz = b.n2; }
         PSampleCoef cf{st.c1, st.c2, coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log, st.t != 0 ? 1.0f : 0.0f};
         API_TRY(e, launch_psample(s, b.x, b.out6, oc, nz, cf, b.x0, xprev, inside, B, H * W));
+        if (variant == 1) {
+            // DPS_yt (main_ddpir.py:439-445): the measurement is noised to level t, the residual is taken at xt = p_sample's sample and
+            // differentiated w.r.t. xt itself -- no backward through the network
+            const float* ny = noise_yt_dev ? noise_yt_dev + (size_t)i * small : nullptr;
+            if (!ny) { API_TRY(e, launch_randn(s, diff, d.seed, (uint64_t)4 * (i + 1) + 1, d.image_offset, B, (size_t)3 * h * w)); ny = diff; }
+            float* nyb = nullptr;
+            API_TRY(e, e->ws.getT("dps#ny", small, &nyb));
+            API_HIP(e, hipMemcpyAsync(nyb, ny, small * sizeof(float), hipMemcpyDeviceToDevice, s));
+            API_TRY(e, resize_down_impl(e, xprev, 1.f, 0.f, down, sf, B, H, W));
+            API_TRY(e, launch_diff_norm(s, d.y_dev, 2.f, -1.f, down, diff, small, part, 256, normv, st.sa_t, st.s1m_t, nyb));
+            API_TRY(e, launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
+            API_TRY(e, launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
+            API_TRY(e, launch_grad_step(s, xprev, gup, normv, lambda_, st.tau, 0.35f, b.x, total));
+            continue;
+        }
         // difference = (2y - 1) - Resizer(x0), norm over the whole batch (utils_model.py:391-392)
         API_TRY(e, resize_down_impl(e, b.x0, 1.f, 0.f, down, sf, B, H, W));
         API_TRY(e, launch_diff_norm(s, d.y_dev, 2.f, -1.f, down, diff, small, part, 256, normv));

@@ -1,6 +1,7 @@
 // Declarations for grad.hip / unet_bwd.hip: the input-gradient path (DPS modes).
 #pragma once
 #include "common.h"
+#include "elem.h"
 
 namespace dpir {
 
@@ -23,7 +24,9 @@ struct PSampleCoef { float c1, c2, pc1, pc2, min_log, max_log, nonzero; };
 Status launch_psample(hipStream_t s, const float* x, const float* out6, int out_ch, const float* noise, const PSampleCoef& cf, float* x0,
                       float* xprev, unsigned char* inside, int B, int HW);
 Status launch_diff_norm(hipStream_t s, const float* y, float ma, float mb, const float* down, float* diff, size_t total, double* part, int nparts,
-                        float* norm_out);
+                        float* norm_out, float sa = 1.f, float s1m = 0.f, const float* noise = nullptr, const LoopDev* lp = nullptr);
+Status launch_grad_step(hipStream_t s, const float* src, const float* gup, const float* norm, float lam, float rho, float tail, float* dst, size_t total,
+                        const StepDev* sp = nullptr);
 Status launch_band_resample_T(hipStream_t s, const float* gout, const float* w, const int* idx, int taps, int P, int L_in, int L_out, int inner,
                               float scale, float* gin);
 Status launch_dps_seed(hipStream_t s, const float* gup, const float* norm, const unsigned char* inside, float c1, float c2, int out_ch, float* dout6,

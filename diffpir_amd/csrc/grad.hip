@@ -285,11 +285,17 @@ Status launch_psample(hipStream_t s, const float* x, const float* out6, int out_
     return Status{};
 }
 
-// diff = meas_a * y + meas_b - down;  partial sums of diff^2 (fp64, one slot per workgroup, folded in order by the next kernel)
-__global__ __launch_bounds__(256) void diff_norm_kernel(const float* y, float ma, float mb, const float* down, float* diff, size_t total, double* part) {
+// diff = measurement - down, measurement = sa (ma y + mb) + s1m noise (DPS_yt: y_t of main_ddpir.py:440; sa = 1, no noise otherwise);
+// partial sums of diff^2 (fp64, one slot per workgroup, folded in order by the next kernel).  lp: y re-read from the loop block.
+__global__ __launch_bounds__(256) void diff_norm_kernel(const float* y, float ma, float mb, float sa, float s1m, const float* noise, const float* down,
+                                                        float* diff, size_t total, double* part, const LoopDev* lp) {
+#pragma clang fp contract(off)
+    if (lp) y = lp->y;
     double s = 0.0;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const float d = (y[i] * ma + mb) - down[i];
+        float m = y[i] * ma + mb;
+        if (noise) m = sa * m + s1m * noise[i];
+        const float d = m - down[i];
         diff[i] = d;
         s += (double)d * (double)d;
     }
@@ -308,8 +314,8 @@ __global__ void norm_fold_kernel(const double* part, int n, float* norm_out) {
     }
 }
 Status launch_diff_norm(hipStream_t s, const float* y, float ma, float mb, const float* down, float* diff, size_t total, double* part, int nparts,
-                        float* norm_out) {
-    hipLaunchKernelGGL(diff_norm_kernel, dim3(nparts), dim3(256), 0, s, y, ma, mb, down, diff, total, part);
+                        float* norm_out, float sa, float s1m, const float* noise, const LoopDev* lp) {
+    hipLaunchKernelGGL(diff_norm_kernel, dim3(nparts), dim3(256), 0, s, y, ma, mb, sa, s1m, noise, down, diff, total, part, lp);
     hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(64), 0, s, part, nparts, norm_out);
     DPIR_HIP(hipGetLastError());
     return Status{};
@@ -380,6 +386,28 @@ __global__ void dps_update_kernel(const float* xprev, const float* direct, const
 Status launch_dps_update(hipStream_t s, const float* xprev, const float* direct, const float* dx_net, float step_scale, float* x, float* grad_out,
                          size_t total) {
     hipLaunchKernelGGL(dps_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xprev, direct, dx_net, step_scale, x, grad_out, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+// x <- x - norm_grad * coef, norm_grad = -gup / norm (gradient of || m - A(x) || w.r.t. x), coef = norm * scale / rho:
+//   first-order data step  (main_ddpir.py:428):  x0 = x0 - norm_grad * norm / rhos[t_i]                        (scale = 1)
+//   DPS_yt                 (main_ddpir.py:444):  x  = xt - norm_grad * lambda * norm / rhos[t_i] * 0.35        (evaluated in that order)
+// rho from the device step block when sp != null.
+__global__ void grad_step_kernel(const float* src, const float* gup, const float* norm, float lam, float rho, float tail, float* dst, size_t total,
+                                 const StepDev* sp) {
+#pragma clang fp contract(off)
+    if (sp) rho = sp->tau;
+    const float nv = norm[0];
+    const float inv = nv > 0.f ? 1.0f / nv : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float ng = -(gup[i] * inv);
+        dst[i] = src[i] - ng * lam * nv / rho * tail;
+    }
+}
+Status launch_grad_step(hipStream_t s, const float* src, const float* gup, const float* norm, float lam, float rho, float tail, float* dst, size_t total,
+                        const StepDev* sp) {
+    hipLaunchKernelGGL(grad_step_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, gup, norm, lam, rho, tail, dst, total, sp);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -140,6 +140,8 @@ def main(argv=None):
     np.random.seed(config.seed)
     eng = Engine(args.device if args.device is not None else local_rank)
     eng.set_precision(str(config.get("engine_precision", "f16x3")))      # before load_state_dict: selects the weight packing
+    if config.generate_mode == "DPS_y0":
+        eng.enable_grad()                  # main_ddpir.py:236-239: DPS_y0 is the one mode that differentiates through the network
     ddist.attach(eng)                      # rccl: ncclCommInitRank on this engine's device
 
     model_config = dict(model_path=os.path.join(config.get("cwd", "") or "", "model_zoo", config.model_name + ".pt"),

@@ -71,22 +71,25 @@ class LoopConfig:
         # ddim_sample is accepted: with model_output_type=pred_xstart it selects the same x0 prediction and the same number
         # of RNG draws as p_sample (utils_model.py:219-240; tests/golden/model_fn.npz).  iter_num_U > 1 cannot be mirrored:
         # the reference raises IndexError on `seq[i+1]` at its last step (main_ddpir.py:448-451 with u < iter_num_U-1).
-        if self.generate_mode not in GENERATE_MODES or self.model_output_type != "pred_xstart" or not self.sub_1_analytic \
-                or self.iter_num_U != 1:
+        if not self.sub_1_analytic and not (self.generate_mode == "DiffPIR" and self.task == "sr"):
+            # main_ddpir.py:420-430: the first-order data step differentiates through degrade_op, which only exists for task sr
+            # (Resizer) in a runnable form (deblur: SURVEY Q1; inpaint: "TODO first order solver for inpainting")
+            raise NotImplementedError("sub_1_analytic=false is implemented for generate_mode DiffPIR, task 'sr'")
+        if self.generate_mode not in GENERATE_MODES or self.model_output_type != "pred_xstart" or self.iter_num_U != 1:
             raise NotImplementedError("only generate_mode in (DiffPIR, repaint, vanilla), model_output_type=pred_xstart, "
-                                      "sub_1_analytic=true, iter_num_U=1 are on the accelerated path (SURVEY.md 8f); DPS_y0 is the "
-                                      "gradient-based mode that is built (task sr)")
-        if self.generate_mode == "DPS_y0":
-            # main_ddpir.py:370-373, 434-438.  Runnable in the reference for task 'sr' only: the deblurring operator raises at :302
-            #  and the inpainting branch never defines xt.  DPS_yt / first-order (sub_1_analytic: false) are not built.
+                                      "iter_num_U=1 are on the accelerated path (SURVEY.md 8f); the gradient-based modes DPS_y0 / DPS_yt and "
+                                      "sub_1_analytic=false exist for task sr")
+        if self.generate_mode in ("DPS_y0", "DPS_yt"):
+            # main_ddpir.py:370-373, 433-445.  Runnable in the reference for task 'sr' only: the deblurring operator raises at :302
+            #  and the inpainting branch never defines xt.
             if self.task != "sr":
-                raise NotImplementedError("generate_mode DPS_y0 is implemented for task 'sr' (the only one the reference can run)")
+                raise NotImplementedError("generate_mode DPS_y0 / DPS_yt are implemented for task 'sr' (the only one the reference can run)")
         elif self.generate_mode != "DiffPIR" and self.task != "inpaint":
             # main_ddpir.py:448: outside DiffPIR mode x is only re-noised for inpainting; other tasks would leave x untouched
             raise NotImplementedError("generate_mode repaint / vanilla are inpainting modes in the reference")
 
 
-GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2, "DPS_y0": 3}
+GENERATE_MODES = {"DiffPIR": 0, "repaint": 1, "vanilla": 2, "DPS_y0": 3, "DPS_yt": 4}
 
 
 def t_start_of(cfg: LoopConfig, reduced) -> int:
@@ -144,7 +147,7 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     Returns a DeviceArray [B,3,H,W] = x_0 in [0,1] (un-clamped, main_ddpir.py:470), and the u8 NHWC
     array as well when return_u8."""
     cfg.check_supported()
-    if cfg.generate_mode == "DPS_y0":
+    if cfg.generate_mode in ("DPS_y0", "DPS_yt"):
         return _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8)
     dt, steps, arr = _steps(cfg)
     keep = []
@@ -198,6 +201,7 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     d.seed, d.image_offset = seed, image_offset
     d.use_graph, d.skip_dead_final_eval = int(use_graph), int(skip_dead_final_eval)
     d.generate_mode = GENERATE_MODES[cfg.generate_mode]
+    d.first_order = 0 if cfg.sub_1_analytic else 1
     if out_f32 is None:
         out_f32 = engine.empty((B, 3, H, W))
     if out_u8 is None and return_u8:
@@ -211,10 +215,11 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
 
 
 def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8):
-    """generate_mode 'DPS_y0' (main_ddpir.py:370-373, 434-438): dpir_run_dps_loop.  Host noise order: init, then ONE p_sample draw per
-    step (there is no re-noising in this mode, main_ddpir.py:448)."""
+    """generate_mode 'DPS_y0' / 'DPS_yt' (main_ddpir.py:370-373, 433-445): dpir_run_dps_loop.  Host noise order: init, then per step the
+    p_sample draw and (DPS_yt, non-final steps) the y_t draw; there is no re-noising in these modes (main_ddpir.py:448)."""
     from .schedule import DiffusionTables
-    if not engine.grad:
+    yt_mode = cfg.generate_mode == "DPS_yt"
+    if not yt_mode and not engine.grad:
         raise EngineError("generate_mode DPS_y0 needs Engine.enable_grad() before the model is loaded")
     dt, steps, arr = _steps(cfg)
     dtab = DiffusionTables.make(cfg.num_train_timesteps)
@@ -235,25 +240,32 @@ def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_off
         lab = np.ascontiguousarray(labels, dtype=np.int64)
         d.labels_host = lab.ctypes.data
     keep = [yd]
-    nps = None
+    nps = nyt = None
     if noise_source == "host":
         if noise_fn is None:
             raise EngineError("noise_source='host' needs noise_fn")
         init = np.asarray(noise_fn((B, 3, H, W)), dtype=np.float32)
-        ps = np.stack([np.asarray(noise_fn((B, 3, H, W)), dtype=np.float32) for _ in steps])
-        di, nps = engine.to_device(init), engine.to_device(ps)
+        ps, yt = [], []
+        for st in steps:
+            ps.append(np.asarray(noise_fn((B, 3, H, W)), dtype=np.float32))
+            yt.append(np.asarray(noise_fn((B, 3, h, w)), dtype=np.float32) if yt_mode and not st["last"] else np.zeros((B, 3, h, w), np.float32))
+        di, nps = engine.to_device(init), engine.to_device(np.stack(ps))
         keep += [di, nps]
+        if yt_mode:
+            nyt = engine.to_device(np.stack(yt))
+            keep.append(nyt)
         d.noise_init_dev = di.ptr
     elif noise_source != "device":
         raise ValueError("noise_source must be 'host' or 'device'")
     d.seed, d.image_offset = seed, image_offset
     d.skip_dead_final_eval = int(skip_dead_final_eval)
-    d.generate_mode = GENERATE_MODES["DPS_y0"]
+    d.generate_mode = GENERATE_MODES[cfg.generate_mode]
     if out_f32 is None:
         out_f32 = engine.empty((B, 3, H, W))
     if out_u8 is None and return_u8:
         out_u8 = engine.empty((B, H, W, 3), np.uint8)
-    engine._check(engine.lib.dpir_run_dps_loop(engine.h, C.byref(d), arr, coefs, len(steps), _ptr(nps), 1.0, _ptr(out_f32), _ptr(out_u8)))
+    engine._check(engine.lib.dpir_run_dps_loop(engine.h, C.byref(d), arr, coefs, len(steps), 1 if yt_mode else 0, float(cfg.lambda_),
+                                               _ptr(nps), _ptr(nyt), 1.0, _ptr(out_f32), _ptr(out_u8)))
     engine.sync()
     return (out_f32, out_u8) if return_u8 else out_f32
 

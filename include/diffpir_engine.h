@@ -205,7 +205,9 @@ typedef struct dpir_loop_desc {
      * is re-drawn at the current noise level before every denoiser call, no prox), 2 vanilla (inpainting only: no
      * conditioning inside the loop).  Re-noising is applied in all three (main_ddpir.py:448). */
     int32_t generate_mode;
-    int32_t reserved0;
+    /* 1: sub_1_analytic = false -- the first-order data step of main_ddpir.py:420-430 instead of the closed-form prox:
+     * x0 <- x0 - d||(2y-1) - Resizer(x0)|| / dx0 * ||.|| / rho (super-resolution tasks, DiffPIR mode; no network backward) */
+    int32_t first_order;
     const float* noise_rp_dev;    /* repaint, host-fed noise: [n_steps,B,3,H,W] in step order; NULL -> device Philox (draw 3) */
 } dpir_loop_desc;
 
@@ -232,10 +234,14 @@ typedef struct dpir_dps_coef { float pc1, pc2, min_log, max_log; } dpir_dps_coef
  *   xt, x0 = p_sample(x)                       (model_fn 'pred_x_prev_and_start', utils_model.py:207-258)
  *   norm   = || (2y - 1) - Resizer(x0) ||_2    over the whole batch          (grad_and_value)
  *   x      = xt - step_scale * d norm / d x    (main_ddpir.py:437, step_scale = 1), no re-noising (:448)
+ * variant 1 = 'DPS_yt' (main_ddpir.py:439-445): y_t = sa_t (2y-1) + s1m_t n;  norm = || y_t - Resizer(xt) ||_2;
+ *   x = xt - d norm / d xt * lambda * norm / rho_t * 0.35   -- differentiated w.r.t. xt itself, no network backward (gradient mode not needed).
  * d / steps_host as in dpir_run_loop (task DPIR_TASK_SR_BLUR or _SR_CUBIC; k / mask / n1 / n2 unused); coefs_host [n_steps];
- * noise_ps_dev: host-fed p_sample noise [n_steps, B,3,H,W] in step order or NULL -> device Philox (stream 4*(step+1)). */
+ * noise_ps_dev: host-fed p_sample noise [n_steps, B,3,H,W] in step order or NULL -> device Philox (stream 4*(step+1));
+ * noise_yt_dev (variant 1): host-fed y_t noise [n_steps, B,3,H/sf,W/sf] or NULL -> Philox (stream 4*(step+1)+1). */
 int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, const dpir_dps_coef* coefs_host, int n_steps,
-                      const float* noise_ps_dev, float step_scale, float* out_f32_dev, uint8_t* out_u8_dev);
+                      int variant, float lambda_, const float* noise_ps_dev, const float* noise_yt_dev, float step_scale,
+                      float* out_f32_dev, uint8_t* out_u8_dev);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------ */
 /* One process and one engine per GPU; images are block-partitioned over ranks, no exchange inside the loop (the reference is

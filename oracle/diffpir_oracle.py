@@ -100,7 +100,8 @@ class LoopConfig:
     T: int = 1000
     beta_start: float = 0.0001
     beta_end: float = 0.02
-    generate_mode: str = "DiffPIR"       # DiffPIR | repaint | vanilla (the latter two: inpainting only)
+    generate_mode: str = "DiffPIR"       # DiffPIR | repaint | vanilla (the latter two: inpainting only) | DPS_y0 | DPS_yt (task sr)
+    sub_1_analytic: bool = True          # False: first-order data step (main_ddpir.py:420-430; runnable for task sr)
     noise_init_img: object = "max"       # 'max' or a noise level in /255 units (main_ddpir.py:197-200)
 
     @property
@@ -322,11 +323,13 @@ def p_sample_prev_and_start(sd, hp, x, t_step: int, dtab: DiffusionTables, noise
 
 
 def restore_dps_y0(sd, hp, cfg: LoopConfig, y, noise_fn: Callable, y_label=None, trace: Optional[list] = None):
-    """generate_mode 'DPS_y0' for task 'sr' (main_ddpir.py:370-373, 434-438 with utils_model.grad_and_value :390-394; the
+    """generate_mode 'DPS_y0' / 'DPS_yt' for task 'sr' (main_ddpir.py:370-373, 433-445 with utils_model.grad_and_value :390-394; the
     deblurring variant cannot run in the reference as shipped, SURVEY Q1, and the inpainting branch never defines xt):
-        xt, x0 = p_sample(x);   norm = || (2y - 1) - Resizer(x0) ||_2 over the WHOLE batch;   x <- xt - d norm / d x
+        DPS_y0:  xt, x0 = p_sample(x);   norm = || (2y - 1) - Resizer(x0) ||_2 over the WHOLE batch;   x <- xt - d norm / d x
+        DPS_yt:  y_t = sa_t (2y - 1) + s1m_t n;   norm = || y_t - Resizer(xt) ||_2;   x <- xt - d norm / d xt * lambda * norm / rho_t * 0.35
+                 (no backward through the network)
     No re-noising (main_ddpir.py:448 is DiffPIR / inpainting only); the final step's denoiser call is dead.  RNG order: init,
-    then one p_sample draw per step."""
+    then per step the p_sample draw [and, DPS_yt, the y_t draw]."""
     if cfg.task != "sr":
         raise ValueError("DPS_y0 is runnable in the reference for task 'sr' only")
     dt, steps = step_tables(cfg)
@@ -339,12 +342,21 @@ def restore_dps_y0(sd, hp, cfg: LoopConfig, y, noise_fn: Callable, y_label=None,
         t_i = st["t_i"]
         if t_i > t_start:
             continue
-        x = x.detach().requires_grad_()
+        yt_mode = cfg.generate_mode == "DPS_yt"
+        x = x.detach()
+        if not yt_mode:
+            x = x.requires_grad_()
         t_step = find_nearest(dt.reduced, st["curr_sigma"] * 255 / 255.0)
         xt, x0 = p_sample_prev_and_start(sd, hp, x, t_step, dtab, noise_fn(x), y_label)
         if trace is not None:
             trace.append(("x0", t_i, x0.detach().clone()))
-        if not st["last"]:
+        if not st["last"] and yt_mode:
+            y_t = dt.sqrt_ac[t_i] * (2 * y - 1) + dt.sqrt_1m_ac[t_i] * noise_fn(y)
+            xt = xt.detach().requires_grad_()
+            norm = torch.linalg.norm(y_t - resizer_apply(xt, 1.0 / cfg.sf))
+            norm_grad = torch.autograd.grad(outputs=norm, inputs=xt)[0]
+            x = (xt - norm_grad * cfg.lambda_ * norm / st["tau"] * 0.35).detach()
+        elif not st["last"]:
             difference = (2 * y - 1) - resizer_apply(x0, 1.0 / cfg.sf)
             norm = torch.linalg.norm(difference)
             norm_grad = torch.autograd.grad(outputs=norm, inputs=x)[0]
@@ -402,6 +414,14 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
             tau = st["tau"].repeat(1, 1, 1, 1)
             if cfg.generate_mode != "DiffPIR":
                 pass                                # main_ddpir.py:385: the data-fidelity step is DiffPIR-only
+            elif not cfg.sub_1_analytic:
+                # first-order solver (main_ddpir.py:420-430): x0 <- x0 - d||m - A(x0)|| / dx0 * ||.|| / rho, m = 2y - 1 (task sr)
+                if cfg.task != "sr":
+                    raise ValueError("the first-order data step is runnable in the reference for task 'sr' only")
+                x0 = x0.detach().requires_grad_()
+                norm = torch.linalg.norm((2 * y - 1) - resizer_apply(x0, 1.0 / cfg.sf))
+                norm_grad = torch.autograd.grad(outputs=norm, inputs=x0)[0]
+                x0 = (x0 - norm_grad * norm / st["tau"]).detach()
             elif cfg.task == "inpaint":
                 x0 = prox_mask(x0, y, mask, tau, cfg.guidance_scale)
             elif cfg.task == "deblur" or cfg.sr_mode == "blur":

@@ -57,6 +57,18 @@ def main():
     ng = [v for n, _, v in tr if n == "norm_grad"][0].numpy()
     out.update(dps_y=case["y"], dps_gt=case["gt"], dps_out=ref, dps_seed=np.array(81), dps_nfe=np.array(5), dps_norm_grad0=ng)
     print("DPS_y0 5-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "| first norm_grad max", float(np.abs(ng).max()), flush=True)
+    # DPS_yt (main_ddpir.py:439-445; its step is 0.35 norm sigma_bar_t^2 / sigma^2 whatever lambda is, so it is only tame from a low
+    # t_start) and the first-order data step of the DiffPIR loop (sub_1_analytic: false, :420-430)
+    cfg = do.LoopConfig("sr", 10, 12.75 / 255, 600.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
+    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(82)).numpy()
+    ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(82)).numpy()
+    out.update(dpsyt_out=ref, dpsyt_seed=np.array(82))
+    print("DPS_yt loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()), flush=True)
+    cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6000.0, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
+    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
+    ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
+    out.update(fo_out=ref, fo_seed=np.array(83))
+    print("first-order loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()), flush=True)
     vjp_case(out, "vjp_ffhq64", uo.ffhq_hp(), 1, 64, 42)
     np.savez_compressed(os.path.join(OUT, "dps.npz"), **out)
     print("wrote dps.npz")

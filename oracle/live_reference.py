@@ -130,10 +130,22 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
                     trace.append(("norm_grad", int(t_i), norm_grad.clone()))
                 x = xt - norm_grad * 1.
                 x = x.detach_()
+            elif seq[i] != seq[-1] and gen_mode == 'DPS_yt':               # main_ddpir.py:439-445
+                y_t = sqrt_alphas_cumprod[t_i] * (2 * y - 1) + sqrt_1m_alphas_cumprod[t_i] * torch.randn_like(y)
+                measurement = y_t / 2 + 0.5 if cfg.task == "deblur" else y_t
+                norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=xt, x_hat=xt, measurement=measurement)
+                x = xt - norm_grad * cfg.lambda_ * norm / (rhos[t_i]) * 0.35
+                x = x.detach_()
             elif seq[i] != seq[-1]:
                 tau = rhos[t_i].float().repeat(1, 1, 1, 1)
                 if gen_mode != 'DiffPIR':
                     pass                                                   # main_ddpir.py:385: step 2 is DiffPIR-only
+                elif not getattr(cfg, "sub_1_analytic", True):             # main_ddpir.py:420-430: first-order solver
+                    x0 = x0.requires_grad_()
+                    measurement = y if cfg.task == "deblur" else 2 * y - 1
+                    norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=x0, x_hat=x0, measurement=measurement)
+                    x0 = x0 - norm_grad * norm / (rhos[t_i])
+                    x0 = x0.detach_()
                 elif cfg.task == "inpaint":
                     x0_p = (mask * (2 * y - 1) + tau * x0).div(mask + tau)
                     x0 = x0 + cfg.guidance_scale * (x0_p - x0)

@@ -117,7 +117,35 @@ def test_dps_y0_loop_matches_live_reference_fixture(golden, precision):
         e.close()
 
 
+def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
+    """The two gradient modes that need no network backward: DPS_yt (main_ddpir.py:439-445) and the first-order data step of the
+    DiffPIR loop (sub_1_analytic: false, :420-430; replayed step graph), task sr x4, against the reference's own runs."""
+    g = golden("dps")
+    hp = uo.tiny_hp()
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision("f16x3")
+        make_model(e, hp)
+        scale = float(np.abs(g["dpsyt_out"]).max())
+        cfg = restore.LoopConfig(task="sr", iter_num=10, lambda_=600.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
+        out = restore.restore_batch(e, cfg, g["dps_y"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["dpsyt_seed"]))).numpy()
+        err = float(np.abs(out - g["dpsyt_out"]).max())
+        print(f"DPS_yt vs LIVE reference: max|diff| {err:.3e} (output range {scale:.2f})")
+        assert err < 1e-4 * max(1.0, scale)
+        assert np.isfinite(restore.restore_batch(e, cfg, g["dps_y"], noise_source="device", seed=4).numpy()).all()
+        cfg = restore.LoopConfig(task="sr", iter_num=6, lambda_=6000.0, zeta=0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
+        for graph in (False, True):
+            out = restore.restore_batch(e, cfg, g["dps_y"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["fo_seed"])), use_graph=graph).numpy()
+            err = float(np.abs(out - g["fo_out"]).max())
+            print(f"first-order data step, graph={graph}, vs LIVE reference: max|diff| {err:.3e} (output range {np.abs(g['fo_out']).max():.2f})")
+            assert err < 1e-4
+    finally:
+        e.close()
+
+
 def test_dps_rejects_tasks_the_reference_cannot_run():
     cfg = restore.LoopConfig(task="deblur", iter_num=4, generate_mode="DPS_y0")
     with pytest.raises(NotImplementedError):
         cfg.check_supported()
+    with pytest.raises(NotImplementedError):
+        restore.LoopConfig(task="deblur", iter_num=4, sub_1_analytic=False).check_supported()
