@@ -157,7 +157,8 @@ def prox_roofline(eng, case, B, H, sf):
     us = ms / n * 1e3
     byts = PROX_BYTES_PER_IMAGE[sf] * B * (H * H) / 65536
     ach = byts / (us * 1e-6) / 1e12
-    return {"bound": "hbm", "kernel": "rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip)" if sf == 1 else "fft.hip c2c path",
+    return {"bound": "hbm", "kernel": ("rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip half-spectrum path" + ("" if sf == 1 else f", alias-grouped columns, sf = {sf}") + ")")
+            if H in (64, 256) and sf in (1, 2, 4) else "fft.hip c2c path",
             "achieved": round(ach, 4), "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(ach / PEAK_HBM_TBS, 4),
             "us_per_apply": round(us, 2), "algorithmic_bytes": int(byts), "batch": B, "sf": sf, "launches_per_apply": 3}
 

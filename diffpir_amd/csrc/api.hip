@@ -84,6 +84,22 @@ Status dpir_engine::fft2_table(int N, const float2** out) {
     return Status{};
 }
 
+Status dpir_engine::fft2_map(int N, int sf, const Fft2Map** out) {
+    auto key = std::make_pair(N, sf);
+    auto it = fft2_maps.find(key);
+    if (it == fft2_maps.end()) {
+        Fft2Map m;
+        fft2_build_map(N, sf, m.h_slot_col, m.h_col_slot);
+        DPIR_HIP(hipMalloc((void**)&m.slot_col, m.h_slot_col.size() * sizeof(int)));
+        DPIR_HIP(hipMalloc((void**)&m.col_slot, m.h_col_slot.size() * sizeof(int)));
+        DPIR_HIP(hipMemcpy(m.slot_col, m.h_slot_col.data(), m.h_slot_col.size() * sizeof(int), hipMemcpyHostToDevice));
+        DPIR_HIP(hipMemcpy(m.col_slot, m.h_col_slot.data(), m.h_col_slot.size() * sizeof(int), hipMemcpyHostToDevice));
+        it = fft2_maps.emplace(key, std::move(m)).first;
+    }
+    *out = &it->second;
+    return Status{};
+}
+
 Status dpir_engine::resizer(int in_len, int sf, ResizerTab* out) {
     auto key = std::make_pair(in_len, sf);
     auto it = resizers.find(key);
@@ -135,6 +151,7 @@ void dpir_destroy(dpir_engine* e) {
     e->ws.release();
     for (auto& kv : e->fft_plans) (void)hipFree(kv.second.tw);
     for (auto& kv : e->fft2_tw) (void)hipFree(kv.second);
+    for (auto& kv : e->fft2_maps) { (void)hipFree(kv.second.slot_col); (void)hipFree(kv.second.col_slot); }
     for (auto& kv : e->resizers) { (void)hipFree(kv.second.w); (void)hipFree(kv.second.idx); }
     for (void* p : e->user_allocs) (void)hipFree(p);
     e->invalidate_graphs();
@@ -302,11 +319,19 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
         DPIR_TRY(e->ws.getT("prox#psf", (size_t)B * H * W, &psf));
         SolveArgs none{};
         DPIR_TRY(launch_psf_embed_real(s, k, kh, kw, psf, B, H, W));
-        DPIR_TRY(launch_rfft_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, W));
+        DPIR_TRY(launch_rfft_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, W, nullptr, 0, st->slot_col));
         DPIR_TRY(launch_cfft_cols(s, tw, st->FB, none, false, B, H));
-        DPIR_TRY(launch_rfft_rows(s, tw, y, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, W));
+        const float* ysrc = y;
+        if (sf > 1) {      // F(zero-stuffed y) (utils_sisr.py:84-85)
+            float* yup = nullptr;
+            DPIR_TRY(e->ws.getT("prox#yup", (size_t)B * 3 * H * W, &yup));
+            DPIR_TRY(launch_upsample_real(s, y, sf, yup, B * 3, H / sf, W / sf));
+            ysrc = yup;
+        }
+        DPIR_TRY(launch_rfft_rows(s, tw, ysrc, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, W, nullptr, 0, st->slot_col));
         DPIR_TRY(launch_cfft_cols(s, tw, st->FBFy, none, false, B * 3, H));
         DPIR_TRY(launch_precalc_finish2(s, st->FB, st->FBFy, st->F2B, B, (size_t)H * st->WP));
+        if (sf > 1) DPIR_TRY(launch_fold_f2b(s, st->F2B, st->slot_col, H, sf, st->invW, B));
         return Status{};
     }
     FftPlan ph, pw;
@@ -322,7 +347,7 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
     return Status{};
 }
 
-static Status prox_alloc(int sf, int B, int H, int W, ProxState* st) {
+static Status prox_alloc(dpir_engine* e, int sf, int B, int H, int W, ProxState* st) {
     st->B = B; st->H = H; st->W = W; st->sf = sf;
     st->half = fft2_supported(H, W, sf);
     st->WP = st->half ? fft2_padded_width(W) : W;
@@ -331,13 +356,22 @@ static Status prox_alloc(int sf, int B, int H, int W, ProxState* st) {
         hipMalloc((void**)&st->F2B, B * hw * sizeof(float)) != hipSuccess ||
         hipMalloc((void**)&st->FBFy, 3 * B * hw * sizeof(float2)) != hipSuccess)
         return Status{DPIR_ERR_NOMEM, "pre_calculate: hipMalloc failed"};
+    st->invW = nullptr; st->slot_col = nullptr; st->col_slot = nullptr; st->h_col_slot = nullptr;
+    if (st->half && sf > 1) {
+        const dpir_engine::Fft2Map* m = nullptr;
+        DPIR_TRY(e->fft2_map(W, sf, &m));
+        st->slot_col = m->slot_col; st->col_slot = m->col_slot; st->h_col_slot = &m->h_col_slot;
+        if (hipMalloc((void**)&st->invW, (size_t)B * (H / sf) * (W / sf / 2 + 1) * sizeof(float)) != hipSuccess)
+            return Status{DPIR_ERR_NOMEM, "pre_calculate: hipMalloc failed"};
+    }
     return Status{};
 }
 static void prox_release(ProxState* st) {
     if (st->FB) (void)hipFree(st->FB);
     if (st->F2B) (void)hipFree(st->F2B);
     if (st->FBFy) (void)hipFree(st->FBFy);
-    st->FB = nullptr; st->F2B = nullptr; st->FBFy = nullptr;
+    if (st->invW) (void)hipFree(st->invW);
+    st->FB = nullptr; st->F2B = nullptr; st->FBFy = nullptr; st->invW = nullptr;
 }
 
 int dpir_prox_fft_precalc(dpir_engine* e, const float* y, const float* k, int kh, int kw, int sf, int B, int H, int W, dpir_prox** out) {
@@ -346,7 +380,7 @@ int dpir_prox_fft_precalc(dpir_engine* e, const float* y, const float* k, int kh
     *out = nullptr;
     dpir_prox* p = new (std::nothrow) dpir_prox();
     if (!p) return fail(e, Status{DPIR_ERR_NOMEM, "out of host memory"});
-    Status s = prox_alloc(sf, B, H, W, &p->st);
+    Status s = prox_alloc(e, sf, B, H, W, &p->st);
     if (s.ok()) s = prox_precalc(e, y, k, kh, kw, sf, B, H, W, &p->st);
     if (!s.ok()) { prox_release(&p->st); delete p; return fail(e, s); }
     *out = p;
@@ -385,6 +419,7 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
                 for (int v = 0; v < st.W; ++v) {
                     bool mir = v > st.W / 2;
                     int su = mir ? (st.H - u) % st.H : u, sv = mir ? st.W - v : v;
+                    if (st.h_col_slot) sv = (*st.h_col_slot)[sv];           // sf > 1: alias-grouped column order
                     const char* sp = tmp.data() + (pl * shw + (size_t)su * st.WP + sv) * esz;
                     char* dp = reinterpret_cast<char*>(host_dst) + (pl * hw + (size_t)u * st.W + v) * esz;
                     memcpy(dp, sp, esz);
@@ -421,11 +456,12 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)st.B * 3 * st.H * st.WP, &hbuf));
         hipStream_t s2 = e->stream;
         ProfScope ps2(&e->prof, PC_FFT);
-        DPIR_TRY(launch_rfft_rows(s2, tw, x, pa, pb, alpha, sp, hbuf, st.B * 3, st.W));
-        SolveArgs a2{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp};
+        DPIR_TRY(launch_rfft_rows(s2, tw, x, pa, pb, alpha, sp, hbuf, st.B * 3, st.W, nullptr, 0, st.slot_col));
+        SolveArgs a2{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp, st.invW, st.slot_col};
         DPIR_TRY(launch_cfft_cols(s2, tw, hbuf, a2, true, st.B * 3, st.H));
         float sc = 1.0f / ((float)st.H * (float)st.W);
-        DPIR_TRY(launch_irfft_rows(s2, tw, hbuf, out, sc, oa, ob, (blend_base && g != 1.0f) ? blend_base : nullptr, g, st.B * 3, st.W));
+        DPIR_TRY(launch_irfft_rows(s2, tw, hbuf, out, sc, oa, ob, (blend_base && g != 1.0f) ? blend_base : nullptr, g, st.B * 3, st.W, nullptr,
+                                   st.col_slot));
         return Status{};
     }
     FftPlan ph, pw;
@@ -677,11 +713,11 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         float2* hbuf = nullptr;
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)prox->B * 3 * prox->H * prox->WP, &hbuf));
         ProfScope ps(&e->prof, PC_FFT);
-        DPIR_TRY(launch_rfft_rows(s, tw, b.x, 0.5f, 0.5f, 1.f, b.cur, hbuf, B * 3, W, b.out6, e->net.desc.out_channels));
-        SolveArgs sa{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur};
+        DPIR_TRY(launch_rfft_rows(s, tw, b.x, 0.5f, 0.5f, 1.f, b.cur, hbuf, B * 3, W, b.out6, e->net.desc.out_channels, prox->slot_col));
+        SolveArgs sa{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur, prox->invW, prox->slot_col};
         DPIR_TRY(launch_cfft_cols(s, tw, hbuf, sa, true, B * 3, H));
         RenoiseArgs ra{b.x, b.cur, b.lp, d.noise_n1_dev, d.noise_n2_dev, d.noise_n2_dev ? total : 0, with_n1 ? 1 : 0};
-        DPIR_TRY(launch_irfft_rows(s, tw, hbuf, b.x0, 1.0f / ((float)H * (float)W), 2.f, -1.f, nullptr, 1.f, B * 3, W, &ra));
+        DPIR_TRY(launch_irfft_rows(s, tw, hbuf, b.x0, 1.0f / ((float)H * (float)W), 2.f, -1.f, nullptr, 1.f, B * 3, W, &ra, prox->col_slot));
         DPIR_HIP(hipGetLastError());
         return Status{};
     }
@@ -782,7 +818,7 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
         API_HIP(e, hipStreamSynchronize(e->stream));
         prox_release(&prox);
         e->invalidate_graphs();
-        API_TRY(e, prox_alloc(d.sf, B, H, W, &prox));
+        API_TRY(e, prox_alloc(e, d.sf, B, H, W, &prox));
     }
 
     // per-step scalar table and the per-batch device block -> device (two small H2D copies per batch)

@@ -70,6 +70,8 @@ struct SolveArgs {
     const float2* FBFy;  // [B,3,H,W]
     float alpha; int sf;
     const StepDev* sp;   // non-null: alpha = sp->tau
+    // fft2.hip, sf > 1: mean of F2B over the aliases [B][H/sf][W/sf/2+1] and the slot map of the permuted half-spectrum layout
+    const float* invW = nullptr; const int* slot_col = nullptr;
 };
 Status launch_fft_cols_solve(hipStream_t s, const FftPlan& ph, float2* buf, const SolveArgs& a, int B, int H, int W);
 // inverse rows with real output: out = Re(ifft_row)*oa + ob, optionally blended: out = base + g*(val - base)
@@ -85,12 +87,16 @@ bool fft2_supported(int H, int W, int sf);
 int fft2_padded_width(int W);
 // eps6 != null (loop only): the row source is x0 = clamp(c1 x - c2 eps) computed on the fly from x and the UNet output
 Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
-                        float2* out, int P, int N, const float* eps6 = nullptr, int out_ch = 0);
+                        float2* out, int P, int N, const float* eps6 = nullptr, int out_ch = 0, const int* slot_col = nullptr);
 // fused re-noise epilogue of the inverse row pass (loop only): x_t <- renoise(x_t, x0'), noise host-fed (n2 [, n1] + step stride,
 // pointers re-read from lp when given) or Philox (n2 == null; seed / image offset from lp)
 struct RenoiseArgs { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
 Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
-                         const float* blend, float g, int P, int N, const RenoiseArgs* ra = nullptr);
+                         const float* blend, float g, int P, int N, const RenoiseArgs* ra = nullptr, const int* col_slot = nullptr);
+// sf > 1 on the half-spectrum path: alias-grouped column permutation (host tables), alias mean of F2B, zero-stuffed real up-sampling
+void fft2_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>& col_slot);
+Status launch_fold_f2b(hipStream_t s, const float* F2B, const int* slot_col, int N, int sf, float* invW, int B);
+Status launch_upsample_real(hipStream_t s, const float* y, int sf, float* out, int P, int h, int w);
 Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N);
 Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw);
 Status launch_psf_embed_real(hipStream_t s, const float* k, int kh, int kw, float* out, int B, int H, int W);

@@ -75,8 +75,11 @@ struct Tape {
 struct ProxState {   // dpir_prox
     int B = 0, H = 0, W = 0, sf = 1;
     float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
-    bool half = false;     // true: natural-order half spectrum [.., H, WP] (fft2.hip); false: bit-reversed full c2c (fft.hip)
+    bool half = false;     // true: half spectrum [.., H, WP] (fft2.hip; columns alias-grouped when sf > 1); false: bit-reversed full c2c (fft.hip)
     int WP = 0;            // stored row length (complex elements)
+    float* invW = nullptr; // half && sf > 1: alias mean of F2B [B][H/sf][W/sf/2+1]
+    const int* slot_col = nullptr; const int* col_slot = nullptr;     // half && sf > 1: device slot maps (engine-owned, fft2_map)
+    const std::vector<int>* h_col_slot = nullptr;                     // host copy (dpir_prox_read)
 };
 
 struct ResizerTab { int in_len = 0, out_len = 0, taps = 0; float* w = nullptr; int* idx = nullptr; };
@@ -95,6 +98,8 @@ struct dpir_engine {
     std::map<std::string, dpir::TapInfo> taps;
     std::map<int, dpir::FftPlan> fft_plans;
     std::map<int, float2*> fft2_tw;              // W_N^m tables (N entries) for fft2.hip
+    struct Fft2Map { int* slot_col = nullptr; int* col_slot = nullptr; std::vector<int> h_slot_col, h_col_slot; };
+    std::map<std::pair<int, int>, Fft2Map> fft2_maps;   // (N, sf) -> alias-grouped column permutation of the half-spectrum layout
     std::map<std::pair<int, int>, dpir::ResizerTab> resizers;   // (in_len, sf)
     std::vector<void*> user_allocs;
     bool collect_taps = true;
@@ -125,6 +130,7 @@ struct dpir_engine {
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);
     dpir::Status fft2_table(int N, const float2** out);
+    dpir::Status fft2_map(int N, int sf, const Fft2Map** out);
     dpir::Status resizer(int in_len, int sf, dpir::ResizerTab* out);
 };
 

@@ -1,6 +1,13 @@
-// fft2: half-spectrum, register-resident FFT path of the data-fidelity prox for sf = 1 (deblurring, the headline
-// configuration) at N = 64 / 256.  Replaces the same reference lines as fft.hip (utils/utils_sisr.py:65-95); the
-// radix-2 / full-c2c kernels of fft.hip remain the general path (sf > 1, other sizes).
+// fft2: half-spectrum, register-resident FFT path of the data-fidelity prox at N = 64 / 256 for sf = 1 (deblurring, the headline
+// configuration) and sf = 2 / 4 (super-resolution, round 3).  Replaces the same reference lines as fft.hip
+// (utils/utils_sisr.py:9-19, 65-95); the radix-2 / full-c2c kernels of fft.hip remain the general path (other sizes).
+//
+// sf > 1: the closed form averages FB*FR over the sf x sf spectral aliases (u + a H/sf, v + b W/sf) -- `splits` + mean in the
+// reference.  On HALF spectra an alias column beyond W/2 is the conjugate of the mirrored row of a stored column, so the sf stored
+// columns {q + b Ws <= W/2} u {W - (q + b Ws)} meet in one fold (index algebra prototyped in oracle/half_spectrum_sr.py).  The
+// spectra are therefore stored COLUMN-PERMUTED: slot sf*q + b holds alias b of fold group q (q <= Ws/2), so that a 16-slot column
+// strip is 16/sf complete groups: 128-byte row segments exactly as for sf = 1, the row aliases u + a Hs stay inside the thread
+// that holds rows t + R k2 of the column FFT (Hs = R * R/sf), and only the column fold and the row mirror go through LDS.
 //
 // Structure (per batch of P = 3B image planes, HBM-bound):
 //   rfft_rows   : two REAL rows are packed into one complex transform (z = a + i b), N = Ra x Rb two-pass FFT held in
@@ -17,6 +24,7 @@
 #include "elem.h"
 #include "philox.h"
 #include "fft_regs.h"
+#include <vector>
 
 namespace dpir {
 
@@ -47,7 +55,7 @@ __device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch,
 struct RowsFuse { const float* eps6; int out_ch; };
 template <int R, int THREADS>
 __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
-                                                         int WP, size_t total_rows, const float2* tw, RowsFuse fu) {
+                                                         int WP, size_t total_rows, const float2* tw, RowsFuse fu, const int* slot_col) {
     constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;                                  // [N]
@@ -98,17 +106,20 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
     for (int k2 = 0; k2 < R; ++k2) z[t + R * k2] = v[k2];
     __syncthreads();
     // un-pack: A[k] = (Z[k] + conj(Z[N-k]))/2, B[k] = (Z[k] - conj(Z[N-k]))/(2i), k = 0..N/2; zero the padding columns
-    for (int k = t; k < WP; k += R) {
+    for (int ks = t; ks < WP; ks += R) {
         float2 A = make_float2(0.f, 0.f), Bv = make_float2(0.f, 0.f);
-        if (k <= N / 2) {
+        // stored slot ks holds spectrum column k: identity for sf = 1, the alias-grouped permutation for sf > 1 (-1: padding)
+        int k = ks <= N / 2 ? ks : -1;
+        if (slot_col) { const int cm = slot_col[ks]; k = cm < 0 ? -1 : (cm & 0xffff); }
+        if (k >= 0) {
             float2 zk = z[k], zn = z[(N - k) & (N - 1)];
             zn.y = -zn.y;
             A = make_float2(0.5f * (zk.x + zn.x), 0.5f * (zk.y + zn.y));
             float2 d = csub(zk, zn);
             Bv = make_float2(0.5f * d.y, -0.5f * d.x);
         }
-        if (va) out[ra * WP + k] = A;
-        if (vb) out[rb * WP + k] = Bv;
+        if (va) out[ra * WP + ks] = A;
+        if (vb) out[rb * WP + ks] = Bv;
     }
 }
 
@@ -120,7 +131,8 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
 struct RenoiseFuse { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
 template <int R, int THREADS>
 __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
-                                                          const float* blend_base, float g, int WP, size_t total_rows, const float2* tw, RenoiseFuse rn) {
+                                                          const float* blend_base, float g, int WP, size_t total_rows, const float2* tw, RenoiseFuse rn,
+                                                          const int* col_slot) {
     constexpr int N = R * R, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
@@ -134,8 +146,9 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
     float2* z = zbuf + slot * (N + 4);
     // Hermitian re-packing: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
     for (int k = t; k <= N / 2; k += R) {
-        float2 A = va ? in[ra * WP + k] : make_float2(0.f, 0.f);
-        float2 Bv = vb ? in[rb * WP + k] : make_float2(0.f, 0.f);
+        const int ks = col_slot ? col_slot[k] : k;          // where column k is stored (sf > 1: permuted)
+        float2 A = va ? in[ra * WP + ks] : make_float2(0.f, 0.f);
+        float2 Bv = vb ? in[rb * WP + ks] : make_float2(0.f, 0.f);
         z[k] = make_float2(A.x - Bv.y, A.y + Bv.x);
         if (k > 0 && k < N / 2) z[N - k] = make_float2(A.x + Bv.y, -A.y + Bv.x);
     }
@@ -245,8 +258,98 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
         }
         fft_two_pass<R, true>(v, t, xch + c * XST, twN);
     }
+    if (MODE == 3) {
+        // sf > 1 (utils_sisr.py:65-75 with `splits`): FBR = mean over the sf x sf aliases of FB * FR, FX = (FR - conj(FB) R~) / alpha with
+        // R = FBR / (invW + alpha) tiled back over the aliases.  Slot c of the strip = alias b = c % sf of fold group c / sf.
+        float alpha = a.sp ? a.sp->tau : a.alpha;
+        const int sf = a.sf, Hs = N / sf, KH = R / sf, ngrp = CS / sf;
+        const int s0 = (blockIdx.x - plane * strips) * CS;               // first slot of the strip
+        const int QW = N / sf / 2 + 1;                                    // fold groups per row: q <= Ws / 2
+        float2* sfold = xch + CS * XST;                                   // [CS][Hs] row-folded FB * FR
+        float2* Rl = sfold + CS * Hs;                                     // [ngrp][Hs]
+        const int n_img = plane / 3;
+        const float2* FB = a.FB + (size_t)n_img * N * WP + col;
+        const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
+        float2 fr[R], fb[R];
+#pragma unroll
+        for (int k2 = 0; k2 < R; ++k2) {
+            const size_t off = (size_t)(t + R * k2) * WP;
+            fr[k2] = cadd(FBFy[off], v[k2]);
+            fb[k2] = FB[off];
+        }
+        // rows u + a Hs of one thread: k2 = k2p + KH a
+        for (int k2p = 0; k2p < KH; ++k2p) {
+            float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+            for (int k2 = 0; k2 < R; ++k2)
+                if (k2 % KH == k2p) acc = cadd(acc, cmul2(fb[k2], fr[k2]));
+            sfold[c * Hs + t + R * k2p] = acc;
+        }
+        __syncthreads();
+        const float inv_n = 1.0f / (float)(sf * sf);
+        for (int item = threadIdx.x; item < ngrp * Hs; item += THREADS) {
+            const int ql = item / Hs, p = item - ql * Hs, pm = (Hs - p) % Hs;
+            const int q = s0 / sf + ql;
+            float2 acc = make_float2(0.f, 0.f);
+            for (int b = 0; b < sf; ++b) {
+                const int cc = ql * sf + b;
+                const int cm = a.slot_col[s0 + cc];
+                if (cm < 0) continue;
+                if (cm >> 16) { const float2 z = sfold[cc * Hs + pm]; acc.x += z.x; acc.y -= z.y; }       // mirrored alias: conj of the mirrored row
+                else acc = cadd(acc, sfold[cc * Hs + p]);
+            }
+            float2 r = make_float2(0.f, 0.f);
+            if (q < QW) {
+                const float den = a.invW[((size_t)n_img * Hs + p) * QW + q] + alpha;
+                r = make_float2(acc.x * inv_n / den, acc.y * inv_n / den);
+            }
+            Rl[ql * Hs + p] = r;
+        }
+        __syncthreads();
+        const int cmine = a.slot_col[s0 + c];
+        const bool mir = cmine >= 0 && (cmine >> 16);
+        const int ql = c / sf;
+#pragma unroll
+        for (int k2 = 0; k2 < R; ++k2) {
+            const int p = t + R * (k2 % KH);
+            float2 rr = mir ? Rl[ql * Hs + (Hs - p) % Hs] : Rl[ql * Hs + p];
+            if (mir) rr.y = -rr.y;
+            const float2 tq = cmulc2(rr, fb[k2]);                          // conj(FB) * R~
+            v[k2] = make_float2((fr[k2].x - tq.x) / alpha, (fr[k2].y - tq.y) / alpha);
+        }
+        fft_two_pass<R, true>(v, t, xch + c * XST, twN);
+    }
 #pragma unroll
     for (int k2 = 0; k2 < R; ++k2) base[(size_t)(t + R * k2) * WP] = v[k2];
+}
+
+// invW[n, p, q] = mean over the sf x sf aliases of F2B (utils_sisr.py:71 `invW = mean(splits(F2B))`), from the permuted half layout
+__global__ void fold_f2b_kernel(const float* F2B, const int* slot_col, int N, int WP, int sf, float* invW, size_t total) {
+    const int Hs = N / sf, QW = N / sf / 2 + 1;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % QW);
+        const int p = (int)((i / QW) % Hs);
+        const size_t n = i / ((size_t)QW * Hs);
+        const float* pl = F2B + n * (size_t)N * WP;
+        float acc = 0.f;
+        for (int b = 0; b < sf; ++b) {
+            const int slot = sf * q + b;
+            const int cm = slot_col[slot];
+            if (cm < 0) continue;
+            const int base_row = (cm >> 16) ? (Hs - p) % Hs : p;          // |FB|^2 is real: the mirrored alias is just the mirrored row
+            for (int a = 0; a < sf; ++a) acc += pl[(size_t)(base_row + a * Hs) * WP + slot];
+        }
+        invW[i] = acc / (float)(sf * sf);
+    }
+}
+// zero-stuffed up-sampling of the measurement as a REAL image (utils_sisr.upsample, :44-52)
+__global__ void upsample_real_kernel(const float* y, int sf, float* out, int h, int w, size_t total) {
+    const int H = h * sf, W = w * sf;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int X = (int)(i % W), Y = (int)((i / W) % H);
+        const size_t p = i / ((size_t)H * W);
+        out[i] = (Y % sf == 0 && X % sf == 0) ? y[(p * h + Y / sf) * w + X / sf] : 0.f;
+    }
 }
 
 // FBFy <- conj(FB) * F(y); F2B = |FB|^2 on the padded half-spectrum layout
@@ -271,7 +374,20 @@ __global__ void psf_embed_real_kernel(const float* k, int kh, int kw, float* out
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-bool fft2_supported(int H, int W, int sf) { return sf == 1 && H == W && (H == 256 || H == 64); }
+bool fft2_supported(int H, int W, int sf) { return (sf == 1 || sf == 2 || sf == 4) && H == W && (H == 256 || H == 64); }
+// slot -> (column | mirrored << 16) or -1 (padding), and column -> canonical slot, for the alias-grouped layout of sf > 1
+void fft2_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>& col_slot) {
+    const int WP = fft2_padded_width(N), Ws = N / sf;
+    slot_col.assign(WP, -1);
+    col_slot.assign(N / 2 + 1, -1);
+    for (int q = 0; q <= Ws / 2; ++q)
+        for (int b = 0; b < sf; ++b) {
+            const int c = q + b * Ws;
+            const int col = c <= N / 2 ? c : N - c, mir = c <= N / 2 ? 0 : 1;
+            slot_col[sf * q + b] = col | (mir << 16);
+            if (col_slot[col] < 0 || (!mir && (slot_col[col_slot[col]] >> 16))) col_slot[col] = sf * q + b;      // prefer the direct copy
+        }
+}
 int fft2_padded_width(int W) { const int cs = 16; return (W / 2 + 1 + cs - 1) / cs * cs; }   // multiple of the column strip
 
 constexpr int ROW_THREADS = 64;    // small workgroups: at B = 16 the whole prox is ~40 MB, concurrency comes from block count
@@ -284,27 +400,27 @@ static size_t cols_lds() { return (size_t)(R * R + (ColCfg<R>::THREADS / R) * (R
 
 template <int R>
 static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
-                          const float2* tw, RowsFuse fu) {
+                          const float2* tw, RowsFuse fu, const int* slot_col) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
     auto fn = rfft_rows_kernel<R, ROW_THREADS>;
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw, fu);
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw, fu, slot_col);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float pa, float pb, float pm, const StepDev* sp,
-                        float2* out, int P, int N, const float* eps6, int out_ch) {
+                        float2* out, int P, int N, const float* eps6, int out_ch, const int* slot_col) {
     if (eps6 && !sp) return invalid("rfft_rows: the fused x0 prologue reads its coefficients from the device step block");
     const RowsFuse fu{eps6, out_ch};
-    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN, fu) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN, fu);
+    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col);
 }
 
 template <int R>
 static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
-                           int P, int N, const float2* tw, RenoiseFuse rn) {
+                           int P, int N, const float2* tw, RenoiseFuse rn, const int* col_slot) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
@@ -312,16 +428,16 @@ static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float sc
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
     hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
-                       rows, tw, rn);
+                       rows, tw, rn, col_slot);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, float* out, float scale, float oa, float ob,
-                         const float* blend, float g, int P, int N, const RenoiseArgs* ra) {
+                         const float* blend, float g, int P, int N, const RenoiseArgs* ra, const int* col_slot) {
     RenoiseFuse rn{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
-    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn)
-                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn);
+    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot)
+                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot);
 }
 
 template <int R, int MODE>
@@ -329,16 +445,34 @@ static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P
     int WP = fft2_padded_width(N);
     constexpr int COL_THREADS = ColCfg<R>::THREADS;
     constexpr int CS = COL_THREADS / R;
+    size_t extra = 0;
+    if (MODE == 3) {
+        if (a.sf < 2 || R % a.sf || CS % a.sf || !a.invW || !a.slot_col) return invalid("cfft_cols: bad sf > 1 arguments");
+        extra = ((size_t)CS * (N / a.sf) + (size_t)(CS / a.sf) * (N / a.sf)) * sizeof(float2);
+    }
     auto fn = cfft_cols_kernel<R, MODE, COL_THREADS>;
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), cols_lds<R>(), s, buf, a, WP, tw);
+    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), cols_lds<R>() + extra, s, buf, a, WP, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N) {
+    if (solve && a.sf > 1) return N == 256 ? cfft_cols_RM<16, 3>(s, buf, a, P, N, twN) : cfft_cols_RM<8, 3>(s, buf, a, P, N, twN);
     if (N == 256) return solve ? cfft_cols_RM<16, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<16, 0>(s, buf, a, P, N, twN);
     return solve ? cfft_cols_RM<8, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<8, 0>(s, buf, a, P, N, twN);
+}
+Status launch_fold_f2b(hipStream_t s, const float* F2B, const int* slot_col, int N, int sf, float* invW, int B) {
+    const size_t total = (size_t)B * (N / sf) * (N / sf / 2 + 1);
+    hipLaunchKernelGGL(fold_f2b_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F2B, slot_col, N, fft2_padded_width(N), sf, invW, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_upsample_real(hipStream_t s, const float* y, int sf, float* out, int P, int h, int w) {
+    const size_t total = (size_t)P * h * sf * w * sf;
+    hipLaunchKernelGGL(upsample_real_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, y, sf, out, h, w, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
 }
 Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw) {
     size_t total = (size_t)B * 3 * hw;

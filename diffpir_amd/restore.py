@@ -148,6 +148,8 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     array as well when return_u8."""
     cfg.check_supported()
     if cfg.generate_mode in ("DPS_y0", "DPS_yt"):
+        if predrawn is not None or mask is not None:
+            raise NotImplementedError("DPS modes take host noise through noise_fn (their draw order differs from the DiffPIR loop's) and no mask")
         return _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8)
     dt, steps, arr = _steps(cfg)
     keep = []

@@ -6,7 +6,7 @@ import diffpir_amd
 from diffpir_amd import synth, utils_sisr as sr
 
 eng = diffpir_amd.Engine(0)
-for (B, H, sf) in ((16, 256, 1), (64, 256, 1), (16, 256, 4), (8, 512, 4)):
+for (B, H, sf) in ((16, 256, 1), (64, 256, 1), (16, 256, 4), (32, 256, 4), (32, 256, 2), (8, 512, 4)):
     case = synth.make_case("deblur", B, H, H, seed=1, ksize=25) if sf == 1 else None
     rng = np.random.default_rng(0)
     if sf == 1:
