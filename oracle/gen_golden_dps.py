@@ -64,7 +64,7 @@ def main():
     ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(82)).numpy()
     out.update(dpsyt_out=ref, dpsyt_seed=np.array(82))
     print("DPS_yt loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()), flush=True)
-    cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6000.0, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
+    cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6.0e5, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
     ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
     ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
     out.update(fo_out=ref, fo_seed=np.array(83))

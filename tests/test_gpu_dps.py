@@ -133,7 +133,7 @@ def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
         print(f"DPS_yt vs LIVE reference: max|diff| {err:.3e} (output range {scale:.2f})")
         assert err < 1e-4 * max(1.0, scale)
         assert np.isfinite(restore.restore_batch(e, cfg, g["dps_y"], noise_source="device", seed=4).numpy()).all()
-        cfg = restore.LoopConfig(task="sr", iter_num=6, lambda_=6000.0, zeta=0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
+        cfg = restore.LoopConfig(task="sr", iter_num=6, lambda_=6.0e5, zeta=0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
         for graph in (False, True):
             out = restore.restore_batch(e, cfg, g["dps_y"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["fo_seed"])), use_graph=graph).numpy()
             err = float(np.abs(out - g["fo_out"]).max())

@@ -282,7 +282,7 @@ def test_dps_tables_vjp_and_loop_match_live_reference(golden):
     cfg = do.LoopConfig("sr", 10, 12.75 / 255, 600.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
     out = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(int(g["dpsyt_seed"])))
     np.testing.assert_allclose(out.numpy(), g["dpsyt_out"], rtol=0, atol=2e-5)
-    cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6000.0, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
+    cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6.0e5, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
     k = torch.from_numpy(synth.make_case("sr", 2, 64, 64, seed=3, sf=4)["k"])
     out = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(int(g["fo_seed"])))
     np.testing.assert_allclose(out.numpy(), g["fo_out"], rtol=0, atol=2e-5)
