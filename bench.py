@@ -42,8 +42,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3    # /opt/skills/guides/MI355X_MICROARCH.md: v_mfm
 PEAK_F16X3_TFLOPS = 2500.0 / 3   # dense f16 MFMA peak / 3 MFMAs per fp32-equivalent product
 PEAK_HBM_TBS = 8.0               # HBM3E spec
 PROX_BYTES_PER_IMAGE = {1: 2_497_536, 4: 2_761_728}     # sf = 1 / sf = 4
-# HBM-side bytes per launch of the roofline kernel class from the committed PMC passes (bench.py cannot run rocprofv3 on
-# itself): see profiles/r02/README.md for the commit, the commands and the arithmetic (FETCH_SIZE doubled per the gfx950 note).
+# HBM-side bytes per launch of the roofline kernel classes from the committed PMC passes (bench.py cannot run rocprofv3 on
+# itself): profiles/pmc_traffic.json is written by tools/pmc_traffic.py from profiles/r03/*_pmc_{FETCH,WRITE}_SIZE.txt (commands:
+# tools/gpu_prof_r3.sh; FETCH_SIZE doubled per the gfx950 note).
 PMC_TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")) else {}
 
 
@@ -157,10 +158,13 @@ def prox_roofline(eng, case, B, H, sf):
     us = ms / n * 1e3
     byts = PROX_BYTES_PER_IMAGE[sf] * B * (H * H) / 65536
     ach = byts / (us * 1e-6) / 1e12
+    tr = PMC_TRAFFIC.get(f"fftprox_sf{sf}_B{B}_{H}")        # committed PMC passes: sum of the apply kernels' fabric-side bytes per launch
+    traffic = None if tr is None else int(sum(v["bytes_per_launch"] for v in tr["kernels"].values()))
     return {"bound": "hbm", "kernel": ("rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip half-spectrum path" + ("" if sf == 1 else f", alias-grouped columns, sf = {sf}") + ")")
             if H in (64, 256) and sf in (1, 2, 4) else "fft.hip c2c path",
             "achieved": round(ach, 4), "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(ach / PEAK_HBM_TBS, 4),
-            "us_per_apply": round(us, 2), "algorithmic_bytes": int(byts), "batch": B, "sf": sf, "launches_per_apply": 3}
+            "us_per_apply": round(us, 2), "algorithmic_bytes": int(byts), "batch": B, "sf": sf, "launches_per_apply": 3,
+            "traffic": traffic, "traffic_source": None if tr is None else tr["source"]}
 
 
 def cpu_baseline_c1(weights, threads):
@@ -328,6 +332,29 @@ def main():
               "degrade_ms": round(t_deg * 1e3, 3), "metrics_ms": round(t_met * 1e3, 3),
               "end_to_end_images_per_s": round(B / t_e2e, 4), "end_to_end_ms": round(t_e2e * 1e3, 1)}
 
+    # ---- the gradient-based mode (DPS_y0, x4 SISR): forward + p_sample + Resizer^T + UNet backward per NFE
+    dps = None
+    if extras and not args.no_alt and args.model == "ffhq":
+        eg = diffpir_amd.Engine(local_rank)
+        eg.set_precision(args.precision)
+        eg.enable_grad()
+        mg = script_util.create_model(**weights.create_model_kwargs(weights.model_hp("ffhq")), engine=eg)
+        mg.load_state_dict(weights.synth_state_dict(weights.model_hp("ffhq"), 0))
+        Bd, nfe_d = 8, 6
+        cd = synth.make_case("sr", Bd, 256, 256, seed=400, sf=4)
+        cfgd = restore.LoopConfig(task="sr", iter_num=nfe_d, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+        yd_ = eg.to_device(cd["y"])
+        restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)          # allocations
+        ta = time.perf_counter()
+        od = restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)
+        eg.sync()
+        td = time.perf_counter() - ta
+        dps = {"what": "generate_mode DPS_y0 (main_ddpir.py:370-373, 434-438), FFHQ topology, x4 SISR 64^2 -> 256^2: per NFE one UNet forward "
+                       f"({args.precision}), p_sample, residual norm, Resizer^T and one UNet input-gradient pass (fp32 MFMA dgrad); eager launches",
+               "batch": Bd, "nfe": nfe_d, "ms_per_nfe": round(td / (nfe_d - 1) * 1e3, 2),
+               "images_per_s_at_100_nfe": round(Bd / (td / (nfe_d - 1) * 100), 4), "finite": bool(np.isfinite(od.numpy()).all())}
+        eg.close()
+
     # ---- secondary measurements in the other arithmetic modes (same inputs, weights, device noise and graph path)
     def other_mode(other):
         eng2 = load(args.model, other)
@@ -409,7 +436,7 @@ def main():
                                        f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
                            "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results",
                            "collective": coll_name},
-                "roofline": roofline, "roofline_prox": prox, "degrade_metrics": f1, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
+                "roofline": roofline, "roofline_prox": prox, "degrade_metrics": f1, "dps_y0": dps, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
         print(json.dumps(line))
     ddist.shutdown()
     if not eng_closed:

@@ -28,24 +28,36 @@
 
 namespace dpir {
 
-// Two-pass N = R*R transform for one "slot" (R cooperating threads, t = 0..R-1).
-//   pass 1 in : thread t holds x[R n1 + t], n1 = 0..R-1            (stride-R elements, offset t)
-//   pass 2 out: thread t holds X[t + R k2], k2 = 0..R-1            (same distribution -> inverse can start from it)
-// xch: this slot's LDS exchange area of R*(R+1) float2; twN: table of W_N^m (cos, -sin), m < N, in LDS.
-template <int R, bool INV>
-__device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch, const float2* twN) {
-    RegFFT<R, INV>::run(v);                                   // over n1 -> Y[k1] for n2 = t
+// Two-pass N = RT * RJ transform for one "slot": RT cooperating threads (t = 0..RT-1) with RJ values each (RJ a multiple of RT;
+// 16 x 16 at N = 256, 8 x 8 at N = 64, 16 x 32 at N = 512).
+//   pass 1 in : thread t holds x[RT j + t], j = 0..RJ-1            (stride-RT elements, offset t): one RJ-point register FFT
+//   pass 2    : RJ / RT register FFTs of RT points per thread (k1 = t + RT s)
+//   out       : thread t holds X[t + RT j], j = 0..RJ-1            (same distribution -> the inverse can start from it)
+// xch: this slot's LDS exchange area of RJ*(RT+1) float2; twN: table of W_N^m (cos, -sin), m < N, in LDS.
+template <int RT, int RJ, bool INV>
+__device__ __forceinline__ void fft_two_pass(float2 (&v)[RJ], int t, float2* xch, const float2* twN) {
+    constexpr int NS = RJ / RT;
+    static_assert(RJ % RT == 0, "RJ must be a multiple of RT");
+    RegFFT<RJ, INV>::run(v);                                  // over j -> Y[k1] for n2 = t
 #pragma unroll
-    for (int k1 = 0; k1 < R; ++k1) {
-        float2 tw = twN[(t * k1) & (R * R - 1)];
+    for (int k1 = 0; k1 < RJ; ++k1) {
+        float2 tw = twN[(t * k1) & (RT * RJ - 1)];
         float2 y = INV ? cmulc2(v[k1], tw) : cmul2(v[k1], tw);
-        xch[k1 * (R + 1) + t] = y;
+        xch[k1 * (RT + 1) + t] = y;
     }
     __syncthreads();
+    float2 u[NS][RT];
 #pragma unroll
-    for (int n2 = 0; n2 < R; ++n2) v[n2] = xch[t * (R + 1) + n2];   // thread k1 = t reads Y[k1][n2]
+    for (int sft = 0; sft < NS; ++sft)
+#pragma unroll
+        for (int n2 = 0; n2 < RT; ++n2) u[sft][n2] = xch[(t + RT * sft) * (RT + 1) + n2];     // thread reads Y[k1 = t + RT s][n2]
     __syncthreads();
-    RegFFT<R, INV>::run(v);                                   // over n2 -> X[t + R k2]
+#pragma unroll
+    for (int sft = 0; sft < NS; ++sft) {
+        RegFFT<RT, INV>::run(u[sft]);                          // over n2 -> X[k1 + RJ k2]
+#pragma unroll
+        for (int k2 = 0; k2 < RT; ++k2) v[k2 * NS + sft] = u[sft][k2];                          // index t + RT (NS k2 + s)
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ rows forward
@@ -53,14 +65,14 @@ __device__ __forceinline__ void fft_two_pass(float2 (&v)[R], int t, float2* xch,
 // Fused loop prologue (dpir_run_loop): when `eps6` is given, the row loaded is not x but the denoiser's clamped x0 prediction
 // x0 = clamp(c1*x - c2*eps, -1, 1) (gaussian_diffusion.py:297,328-333), evaluated while staging -- x0 is never materialised.
 struct RowsFuse { const float* eps6; int out_ch; };
-template <int R, int THREADS>
+template <int R, int RJ, int THREADS>
 __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out,
                                                          int WP, size_t total_rows, const float2* tw, RowsFuse fu, const int* slot_col) {
-    constexpr int N = R * R, SLOTS = THREADS / R;
+    constexpr int N = R * RJ, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;                                  // [N]
-    float2* xch = sm2 + N;                              // [SLOTS][R*(R+1)]
-    float2* zbuf = xch + SLOTS * R * (R + 1);           // [SLOTS][N+4]  natural-order Z of each slot (also the load staging)
+    float2* xch = sm2 + N;                              // [SLOTS][RJ*(R+1)]
+    float2* zbuf = xch + SLOTS * RJ * (R + 1);          // [SLOTS][N+4]  natural-order Z of each slot (also the load staging)
     if (sp) pm = sp->tau;
     for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
@@ -91,19 +103,19 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
         }
     }
     __syncthreads();
-    float2 v[R];
+    float2 v[RJ];
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) {
+    for (int n1 = 0; n1 < RJ; ++n1) {
         int n = R * n1 + t;
         float a = (stage[(2 * slot) * (N + 4) + n] * pa + pb) * pm;
         float b = (stage[(2 * slot + 1) * (N + 4) + n] * pa + pb) * pm;
         v[n1] = make_float2(va ? a : 0.f, vb ? b : 0.f);
     }
     __syncthreads();
-    fft_two_pass<R, false>(v, t, xch + slot * R * (R + 1), twN);
+    fft_two_pass<R, RJ, false>(v, t, xch + slot * RJ * (R + 1), twN);
     float2* z = zbuf + slot * (N + 4);
 #pragma unroll
-    for (int k2 = 0; k2 < R; ++k2) z[t + R * k2] = v[k2];
+    for (int k2 = 0; k2 < RJ; ++k2) z[t + R * k2] = v[k2];
     __syncthreads();
     // un-pack: A[k] = (Z[k] + conj(Z[N-k]))/2, B[k] = (Z[k] - conj(Z[N-k]))/(2i), k = 0..N/2; zero the padding columns
     for (int ks = t; ks < WP; ks += R) {
@@ -129,15 +141,15 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
 //     eps = (x_t - sa_t x0') / s1m_t;   x = sa_p x0' + k1 (q eps + es n1) + k2 n2
 // written over x_t; n1 / n2 are host-fed tensors or Philox draws (same (seed, image, stream, counter) as randn_kernel).
 struct RenoiseFuse { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
-template <int R, int THREADS>
+template <int R, int RJ, int THREADS>
 __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, float* out, float scale, float oa, float ob,
                                                           const float* blend_base, float g, int WP, size_t total_rows, const float2* tw, RenoiseFuse rn,
                                                           const int* col_slot) {
-    constexpr int N = R * R, SLOTS = THREADS / R;
+    constexpr int N = R * RJ, SLOTS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
     float2* xch = sm2 + N;
-    float2* zbuf = xch + SLOTS * R * (R + 1);
+    float2* zbuf = xch + SLOTS * RJ * (R + 1);
     for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
@@ -153,16 +165,16 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
         if (k > 0 && k < N / 2) z[N - k] = make_float2(A.x + Bv.y, -A.y + Bv.x);
     }
     __syncthreads();
-    float2 v[R];
+    float2 v[RJ];
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) v[n1] = z[R * n1 + t];
+    for (int n1 = 0; n1 < RJ; ++n1) v[n1] = z[R * n1 + t];
     __syncthreads();
-    fft_two_pass<R, true>(v, t, xch + slot * R * (R + 1), twN);
+    fft_two_pass<R, RJ, true>(v, t, xch + slot * RJ * (R + 1), twN);
     // stage the block's 2*SLOTS real rows in LDS, then float4 row-contiguous stores (a lane-strided direct store writes
     // 64-byte fragments of 8 different rows per instruction)
     float* stage = reinterpret_cast<float*>(zbuf);          // [2*SLOTS][N + 4] floats (the z area is dead now)
 #pragma unroll
-    for (int k2 = 0; k2 < R; ++k2) {
+    for (int k2 = 0; k2 < RJ; ++k2) {
         int n = t + R * k2;
         stage[(2 * slot) * (N + 4) + n] = (v[k2].x * scale) * oa + ob;
         stage[(2 * slot + 1) * (N + 4) + n] = (v[k2].y * scale) * oa + ob;
@@ -221,24 +233,24 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
 // ------------------------------------------------------------------------------------------------ columns
 // A strip of CS = 256/R columns per workgroup; thread = (column c, t).  MODE 0: forward only; MODE 2: forward ->
 // solve (sf = 1: FX = (FR - conj(FB) * (FB*FR)/(F2B+alpha)) / alpha, FR = FBFy + F(alpha x)) -> inverse.
-template <int R, int MODE, int THREADS>
+template <int R, int RJ, int MODE, int THREADS, int SF>
 __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveArgs a, int WP, const float2* tw) {
-    constexpr int N = R * R, CS = THREADS / R;
+    constexpr int N = R * RJ, CS = THREADS / R;
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
-    float2* xch = sm2 + N;                              // [CS][R*(R+1)+1]  (+1: lanes of a wave walk the slots)
-    constexpr int XST = R * (R + 1) + 1;
+    float2* xch = sm2 + N;                              // [CS][RJ*(R+1)+1]  (+1: lanes of a wave walk the slots)
+    constexpr int XST = RJ * (R + 1) + 1;
     for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int c = threadIdx.x % CS, t = threadIdx.x / CS;     // lanes walk the strip's columns: 128-byte row segments
     const int strips = WP / CS;
     const int plane = blockIdx.x / strips;
     const int col = (blockIdx.x - plane * strips) * CS + c;
     float2* base = buf + (size_t)plane * N * WP + col;
-    float2 v[R];
+    float2 v[RJ];
 #pragma unroll
-    for (int n1 = 0; n1 < R; ++n1) v[n1] = base[(size_t)(R * n1 + t) * WP];
+    for (int n1 = 0; n1 < RJ; ++n1) v[n1] = base[(size_t)(R * n1 + t) * WP];
     __syncthreads();
-    fft_two_pass<R, false>(v, t, xch + c * XST, twN);
+    fft_two_pass<R, RJ, false>(v, t, xch + c * XST, twN);
     if (MODE == 2) {
         float alpha = a.sp ? a.sp->tau : a.alpha;
         const int n_img = plane / 3;
@@ -246,7 +258,7 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
         const float* F2B = a.F2B + (size_t)n_img * N * WP + col;
         const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
 #pragma unroll
-        for (int k2 = 0; k2 < R; ++k2) {
+        for (int k2 = 0; k2 < RJ; ++k2) {
             size_t off = (size_t)(t + R * k2) * WP;
             float2 fr = cadd(FBFy[off], v[k2]);
             float2 fb = FB[off];
@@ -256,13 +268,13 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
             float2 tq = cmulc2(q, fb);                          // conj(FB) * q
             v[k2] = make_float2((fr.x - tq.x) / alpha, (fr.y - tq.y) / alpha);
         }
-        fft_two_pass<R, true>(v, t, xch + c * XST, twN);
+        fft_two_pass<R, RJ, true>(v, t, xch + c * XST, twN);
     }
     if (MODE == 3) {
         // sf > 1 (utils_sisr.py:65-75 with `splits`): FBR = mean over the sf x sf aliases of FB * FR, FX = (FR - conj(FB) R~) / alpha with
         // R = FBR / (invW + alpha) tiled back over the aliases.  Slot c of the strip = alias b = c % sf of fold group c / sf.
         float alpha = a.sp ? a.sp->tau : a.alpha;
-        const int sf = a.sf, Hs = N / sf, KH = R / sf, ngrp = CS / sf;
+        constexpr int sf = SF, Hs = N / SF, KH = RJ / SF, ngrp = CS / SF;
         const int s0 = (blockIdx.x - plane * strips) * CS;               // first slot of the strip
         const int QW = N / sf / 2 + 1;                                    // fold groups per row: q <= Ws / 2
         float2* sfold = xch + CS * XST;                                   // [CS][Hs] row-folded FB * FR
@@ -270,21 +282,18 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
         const int n_img = plane / 3;
         const float2* FB = a.FB + (size_t)n_img * N * WP + col;
         const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
-        float2 fr[R], fb[R];
+        // v <- FR = FBFy + F(alpha x); rows u + a Hs of one thread are k2 = k2p + KH a: fold them while FB * FR is formed
+        float2 sacc[KH];
 #pragma unroll
-        for (int k2 = 0; k2 < R; ++k2) {
+        for (int i = 0; i < KH; ++i) sacc[i] = make_float2(0.f, 0.f);
+#pragma unroll
+        for (int k2 = 0; k2 < RJ; ++k2) {
             const size_t off = (size_t)(t + R * k2) * WP;
-            fr[k2] = cadd(FBFy[off], v[k2]);
-            fb[k2] = FB[off];
+            v[k2] = cadd(FBFy[off], v[k2]);
+            sacc[k2 % KH] = cadd(sacc[k2 % KH], cmul2(FB[off], v[k2]));
         }
-        // rows u + a Hs of one thread: k2 = k2p + KH a
-        for (int k2p = 0; k2p < KH; ++k2p) {
-            float2 acc = make_float2(0.f, 0.f);
 #pragma unroll
-            for (int k2 = 0; k2 < R; ++k2)
-                if (k2 % KH == k2p) acc = cadd(acc, cmul2(fb[k2], fr[k2]));
-            sfold[c * Hs + t + R * k2p] = acc;
-        }
+        for (int i = 0; i < KH; ++i) sfold[c * Hs + t + R * i] = sacc[i];
         __syncthreads();
         const float inv_n = 1.0f / (float)(sf * sf);
         for (int item = threadIdx.x; item < ngrp * Hs; item += THREADS) {
@@ -310,17 +319,17 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
         const bool mir = cmine >= 0 && (cmine >> 16);
         const int ql = c / sf;
 #pragma unroll
-        for (int k2 = 0; k2 < R; ++k2) {
+        for (int k2 = 0; k2 < RJ; ++k2) {
             const int p = t + R * (k2 % KH);
             float2 rr = mir ? Rl[ql * Hs + (Hs - p) % Hs] : Rl[ql * Hs + p];
             if (mir) rr.y = -rr.y;
-            const float2 tq = cmulc2(rr, fb[k2]);                          // conj(FB) * R~
-            v[k2] = make_float2((fr[k2].x - tq.x) / alpha, (fr[k2].y - tq.y) / alpha);
+            const float2 tq = cmulc2(rr, FB[(size_t)(t + R * k2) * WP]);   // conj(FB) * R~   (FB re-read: an L2 hit, not 2 RJ live registers)
+            v[k2] = make_float2((v[k2].x - tq.x) / alpha, (v[k2].y - tq.y) / alpha);
         }
-        fft_two_pass<R, true>(v, t, xch + c * XST, twN);
+        fft_two_pass<R, RJ, true>(v, t, xch + c * XST, twN);
     }
 #pragma unroll
-    for (int k2 = 0; k2 < R; ++k2) base[(size_t)(t + R * k2) * WP] = v[k2];
+    for (int k2 = 0; k2 < RJ; ++k2) base[(size_t)(t + R * k2) * WP] = v[k2];
 }
 
 // invW[n, p, q] = mean over the sf x sf aliases of F2B (utils_sisr.py:71 `invW = mean(splits(F2B))`), from the permuted half layout
@@ -374,7 +383,7 @@ __global__ void psf_embed_real_kernel(const float* k, int kh, int kw, float* out
 }
 
 // ------------------------------------------------------------------------------------------------ launchers
-bool fft2_supported(int H, int W, int sf) { return (sf == 1 || sf == 2 || sf == 4) && H == W && (H == 256 || H == 64); }
+bool fft2_supported(int H, int W, int sf) { return (sf == 1 || sf == 2 || sf == 4) && H == W && (H == 512 || H == 256 || H == 64); }
 // slot -> (column | mirrored << 16) or -1 (padding), and column -> canonical slot, for the alias-grouped layout of sf > 1
 void fft2_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>& col_slot) {
     const int WP = fft2_padded_width(N), Ws = N / sf;
@@ -393,21 +402,22 @@ int fft2_padded_width(int W) { const int cs = 16; return (W / 2 + 1 + cs - 1) / 
 constexpr int ROW_THREADS = 64;    // small workgroups: at B = 16 the whole prox is ~40 MB, concurrency comes from block count
 // 16 columns per strip for both sizes: a strip row is one full 128-byte line (8 columns = half lines cost ~2x the requests)
 template <int R> struct ColCfg { static constexpr int THREADS = 16 * R; };
-template <int R>
-static size_t rows_lds() { return (size_t)(R * R + (ROW_THREADS / R) * R * (R + 1) + (ROW_THREADS / R) * (R * R + 4)) * sizeof(float2); }
-template <int R>
-static size_t cols_lds() { return (size_t)(R * R + (ColCfg<R>::THREADS / R) * (R * (R + 1) + 1)) * sizeof(float2); }
+template <int R, int RJ>
+static size_t rows_lds() { return (size_t)(R * RJ + (ROW_THREADS / R) * RJ * (R + 1) + (ROW_THREADS / R) * (R * RJ + 4)) * sizeof(float2); }
+template <int R, int RJ>
+static size_t cols_lds() { return (size_t)(R * RJ + (ColCfg<R>::THREADS / R) * (RJ * (R + 1) + 1)) * sizeof(float2); }
 
-template <int R>
+template <int R, int RJ>
 static Status rfft_rows_R(hipStream_t s, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int N,
                           const float2* tw, RowsFuse fu, const int* slot_col) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
-    auto fn = rfft_rows_kernel<R, ROW_THREADS>;
+    auto fn = rfft_rows_kernel<R, RJ, ROW_THREADS>;
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, x, pa, pb, pm, sp, out, WP, rows, tw, fu, slot_col);
+    const size_t lds = rows_lds<R, RJ>();
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), lds, s, x, pa, pb, pm, sp, out, WP, rows, tw, fu, slot_col);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -415,19 +425,21 @@ Status launch_rfft_rows(hipStream_t s, const float2* twN, const float* x, float 
                         float2* out, int P, int N, const float* eps6, int out_ch, const int* slot_col) {
     if (eps6 && !sp) return invalid("rfft_rows: the fused x0 prologue reads its coefficients from the device step block");
     const RowsFuse fu{eps6, out_ch};
-    return N == 256 ? rfft_rows_R<16>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col) : rfft_rows_R<8>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col);
+    if (N == 512) return rfft_rows_R<16, 32>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col);
+    return N == 256 ? rfft_rows_R<16, 16>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col) : rfft_rows_R<8, 8>(s, x, pa, pb, pm, sp, out, P, N, twN, fu, slot_col);
 }
 
-template <int R>
+template <int R, int RJ>
 static Status irfft_rows_R(hipStream_t s, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
                            int P, int N, const float2* tw, RenoiseFuse rn, const int* col_slot) {
     int WP = fft2_padded_width(N);
     size_t rows = (size_t)P * N, pairs = (rows + 1) / 2;
     constexpr int SLOTS = ROW_THREADS / R;
-    auto fn = irfft_rows_kernel<R, ROW_THREADS>;
+    auto fn = irfft_rows_kernel<R, RJ, ROW_THREADS>;
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), rows_lds<R>(), s, in, out, scale, oa, ob, blend, g, WP,
+    const size_t lds = rows_lds<R, RJ>();
+    hipLaunchKernelGGL(fn, dim3((unsigned)((pairs + SLOTS - 1) / SLOTS)), dim3(ROW_THREADS), lds, s, in, out, scale, oa, ob, blend, g, WP,
                        rows, tw, rn, col_slot);
     DPIR_HIP(hipGetLastError());
     return Status{};
@@ -436,31 +448,41 @@ Status launch_irfft_rows(hipStream_t s, const float2* twN, const float2* in, flo
                          const float* blend, float g, int P, int N, const RenoiseArgs* ra, const int* col_slot) {
     RenoiseFuse rn{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
     if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
-    return N == 256 ? irfft_rows_R<16>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot)
-                    : irfft_rows_R<8>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot);
+    if (N == 512) return irfft_rows_R<16, 32>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot);
+    return N == 256 ? irfft_rows_R<16, 16>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot)
+                    : irfft_rows_R<8, 8>(s, in, out, scale, oa, ob, blend, g, P, N, twN, rn, col_slot);
 }
 
-template <int R, int MODE>
+template <int R, int RJ, int MODE, int SF = 1>
 static Status cfft_cols_RM(hipStream_t s, float2* buf, const SolveArgs& a, int P, int N, const float2* tw) {
     int WP = fft2_padded_width(N);
     constexpr int COL_THREADS = ColCfg<R>::THREADS;
     constexpr int CS = COL_THREADS / R;
     size_t extra = 0;
     if (MODE == 3) {
-        if (a.sf < 2 || R % a.sf || CS % a.sf || !a.invW || !a.slot_col) return invalid("cfft_cols: bad sf > 1 arguments");
+        if (a.sf != SF || SF < 2 || RJ % SF || CS % SF || !a.invW || !a.slot_col) return invalid("cfft_cols: bad sf > 1 arguments");
         extra = ((size_t)CS * (N / a.sf) + (size_t)(CS / a.sf) * (N / a.sf)) * sizeof(float2);
     }
-    auto fn = cfft_cols_kernel<R, MODE, COL_THREADS>;
+    auto fn = cfft_cols_kernel<R, RJ, MODE, COL_THREADS, SF>;
     static LdsAttrOnce attr;
     DPIR_HIP(attr.set(reinterpret_cast<const void*>(fn), 160 * 1024));
-    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), cols_lds<R>() + extra, s, buf, a, WP, tw);
+    const size_t lds = cols_lds<R, RJ>() + extra;
+    hipLaunchKernelGGL(fn, dim3((unsigned)(P * (WP / CS))), dim3(COL_THREADS), lds, s, buf, a, WP, tw);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N) {
-    if (solve && a.sf > 1) return N == 256 ? cfft_cols_RM<16, 3>(s, buf, a, P, N, twN) : cfft_cols_RM<8, 3>(s, buf, a, P, N, twN);
-    if (N == 256) return solve ? cfft_cols_RM<16, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<16, 0>(s, buf, a, P, N, twN);
-    return solve ? cfft_cols_RM<8, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<8, 0>(s, buf, a, P, N, twN);
+    const int m = !solve ? 0 : (a.sf > 1 ? 3 : 2);
+    if (m == 3 && a.sf != 2 && a.sf != 4) return invalid("cfft_cols: sf must be 2 or 4 on the half-spectrum path");
+#define DPIR_COLS(RT, RJ_)                                                                                              \
+    do {                                                                                                                \
+        if (m == 3) return a.sf == 2 ? cfft_cols_RM<RT, RJ_, 3, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<RT, RJ_, 3, 4>(s, buf, a, P, N, twN); \
+        return m == 2 ? cfft_cols_RM<RT, RJ_, 2>(s, buf, a, P, N, twN) : cfft_cols_RM<RT, RJ_, 0>(s, buf, a, P, N, twN);    \
+    } while (0)
+    if (N == 512) DPIR_COLS(16, 32);
+    if (N == 256) DPIR_COLS(16, 16);
+    DPIR_COLS(8, 8);
+#undef DPIR_COLS
 }
 Status launch_fold_f2b(hipStream_t s, const float* F2B, const int* slot_col, int N, int sf, float* invW, int B) {
     const size_t total = (size_t)B * (N / sf) * (N / sf / 2 + 1);

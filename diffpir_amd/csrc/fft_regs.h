@@ -45,6 +45,29 @@ template <bool INV> struct RegFFT<16, INV> {
             for (int b = a + 1; b < 4; ++b) { float2 t = v[4 * a + b]; v[4 * a + b] = v[4 * b + a]; v[4 * b + a] = t; }
     }
 };
+// 32 = 2 x 16 (decimation in time): X[k] = E[k] + W32^k O[k], X[k + 16] = E[k] - W32^k O[k]
+template <bool INV> struct RegFFT<32, INV> {
+    static __device__ __forceinline__ void run(float2 (&v)[32]) {
+        float2 e[16], o[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) { e[i] = v[2 * i]; o[i] = v[2 * i + 1]; }
+        RegFFT<16, INV>::run(e);
+        RegFFT<16, INV>::run(o);
+        const float c[16] = {1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f, 0.70710678118654752f, 0.55557023301960218f,
+                             0.38268343236508977f, 0.19509032201612825f, 0.f, -0.19509032201612825f, -0.38268343236508977f, -0.55557023301960218f,
+                             -0.70710678118654752f, -0.83146961230254524f, -0.92387953251128674f, -0.98078528040323043f};
+        const float sn[16] = {0.f, 0.19509032201612825f, 0.38268343236508977f, 0.55557023301960218f, 0.70710678118654752f, 0.83146961230254524f,
+                              0.92387953251128674f, 0.98078528040323043f, 1.f, 0.98078528040323043f, 0.92387953251128674f, 0.83146961230254524f,
+                              0.70710678118654752f, 0.55557023301960218f, 0.38268343236508977f, 0.19509032201612825f};
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float2 w = make_float2(c[k], -sn[k]);
+            const float2 t = INV ? cmulc2(o[k], w) : cmul2(o[k], w);
+            v[k] = cadd(e[k], t);
+            v[k + 16] = csub(e[k], t);
+        }
+    }
+};
 template <bool INV> struct RegFFT<8, INV> {
     static __device__ __forceinline__ void run(float2 (&v)[8]) {
         const float h = 0.70710678118654752f;

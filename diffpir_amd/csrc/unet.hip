@@ -297,7 +297,9 @@ struct Fwd {
     PendingConv pending;
     bool grad = false;    // grad mode: classic (unfused) prologues, GroupNorm tables kept, tape recorded
     bool fuse_small;
-    bool emit_skip;       // conv5 emits conv1's operand planes in ResBlocks with a 1x1 skip projection
+    int emit_skip;        // conv5 emits conv1's operand planes in ResBlocks with a 1x1 skip projection: 0 never, 1 when the projection has
+                          // ONE 128-channel output block (each input row is then read exactly once; with two blocks only one of them emits and
+                          // the other re-reads -- measured slower on the ImageNet-256 topology, profiles/r03), 2 always
 
     Status resolve() {
         if (!pending.partial) return Status{};
@@ -460,7 +462,7 @@ struct Fwd {
         // (concat) input feeds both the skip projection and in_layers -- conv5 emits conv1's split operand planes
         const int Cin = in.C();
         const size_t eplane = (size_t)B * (2 * ((Cin + 15) / 16)) * Ho * Wo * 16;
-        if (emit_skip && r.has_skip && r.mode == 0 && r.conv1.w16 && r.skip.w16 && conv6_supported(Ho, Wo) && conv5_supported(B, r.cout, Ho, Wo) &&
+        if ((emit_skip == 2 || (emit_skip == 1 && r.cout <= 128)) && r.has_skip && r.mode == 0 && r.conv1.w16 && r.skip.w16 && conv6_supported(Ho, Wo) && conv5_supported(B, r.cout, Ho, Wo) &&
             Cin % 16 == 0 && Cin <= 1024 && (Ho * Wo) % 256 == 0 && eplane < ((size_t)1 << 32) && !(fuse_small && gn_act_small_supported(Cin, in.H, in.W, 0))) {
             const bool x1 = e->precision == 2;
             float4* prm1 = nullptr;
@@ -605,10 +607,10 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     Fwd f{e, s, ws, B, hoisted ? film_table : film, net.film_rows, hoisted ? 0 : net.film_rows, hoisted ? film_step : nullptr, partial, partial_cap};
     {
         static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
-        static const bool emit_env = !(getenv("DPIR_EMIT_SKIP") && atoi(getenv("DPIR_EMIT_SKIP")) == 0);
+        static const int emit_env = getenv("DPIR_EMIT_SKIP") ? atoi(getenv("DPIR_EMIT_SKIP")) : 1;
         f.grad = e->grad_enabled;
         f.fuse_small = fuse_env && !f.grad;
-        f.emit_skip = emit_env && !f.grad;
+        f.emit_skip = f.grad ? 0 : emit_env;
         if (f.grad) { e->tape.clear(); e->tape.B = B; e->tape.H = H; e->tape.W = W; }
     }
     if (e->collect_taps) e->taps.clear();

@@ -83,6 +83,25 @@ def test_unet_input_gradient_ffhq_topology_64(golden):
         e.close()
 
 
+@pytest.mark.parametrize("tag,hp,B,size", [("ffhq", uo.ffhq_hp(), 1, 256), ("imagenet256", uo.imagenet256_hp(), 2, 64)])
+def test_unet_input_gradient_full_size_and_imagenet_topology(tag, hp, B, size):
+    """The benched network at its real input size (dgrad of the 128 -> 128 and 256 -> 128 @256^2 tiles, GroupNorm backward over
+    65536-pixel planes) and the ImageNet-256 topology (2 ResBlocks per level, 16 attention blocks) against torch.autograd through
+    the oracle restatement (bit-identical to the live reference network, tests/test_oracle_golden.py)."""
+    e, sd = _engine(hp, "f16x3")
+    try:
+        x, gout = _inputs(50 + B, B, size)
+        t = np.array([417, 23][:B])
+        _, dx = e.unet_vjp(e.to_device(x.numpy()), t, e.to_device(gout.numpy()))
+        xr = x.clone().requires_grad_()
+        ref = torch.autograd.grad((uo.unet_forward(sd, hp, xr, torch.from_numpy(t)) * gout).sum(), xr)[0].numpy()
+        err = rel_err(dx.numpy(), ref)
+        print(f"{tag} topology @{size}^2 B={B} input gradient [f16x3 forward]: rel err vs autograd {err:.3e} (|grad| max {np.abs(ref).max():.3f})")
+        assert err < TOL_GRAD
+    finally:
+        e.close()
+
+
 def test_gradient_mode_must_be_enabled_before_load():
     e = diffpir_amd.Engine(0)
     try:
