@@ -164,6 +164,7 @@ struct Conv6Args {
     float2* stat = nullptr;        // optional [B][Cout][conv6_stat_slots(H, W)] epilogue partial sums (no split-K)
     double2* stat_plane = nullptr; // optional [B][Cout] fp64 {sum, sum of squares}, written by the split-K combine
     bool x1 = false;               // single-product mode (f16x1): hi planes / hi weight halves only
+    const float* out_scale_dev = nullptr;      // optional device scalar folded into the output scale (dgrad, unet_bwd.hip)
 };
 bool conv6_supported(int H, int W);
 int conv6_stat_slots(int H, int W);
@@ -183,6 +184,7 @@ struct Conv5Args {
     // optional second product: the split operand planes of the following 3x3 convolution, silu(GroupNorm(src)) per emit_prm,
     // blocked [B][2*ceil(C/16)][HW][8] f16 (act.hip's layout); requires prm == null (the 1x1 itself multiplies the raw input)
     const float4* emit_prm = nullptr; void* emit_hi = nullptr; void* emit_lo = nullptr;
+    const float* out_scale_dev = nullptr;      // optional device scalar folded into the output scale (dgrad)
 };
 bool conv5_supported(int B, int Cout, int H, int W);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);

@@ -22,6 +22,7 @@ struct Conv5K {
     long long total_px;
     const float* zeros;
     float out_scale;
+    const float* out_scale_dev;       // optional device scalar multiplied into out_scale (dgrad)
     unsigned long long* range_ctr;
     // EMIT: the kernel also produces the split operand planes of the ResBlock's first 3x3 convolution from the SAME input rows
     // (GroupNorm affine + SiLU per eprm, f16 hi/lo, blocked [n][C8][HW][8] as act.hip writes them): the concat input of an
@@ -206,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
     const int n4 = ok4 ? (int)(g4 / HW) : 0;
     const size_t base4 = (size_t)n4 * p.Cout * HW + (size_t)(g4 - (long long)n4 * HW);
     const int co0 = co_blk * 128;
+    const float osc = p.out_scale_dev ? p.out_scale * p.out_scale_dev[0] : p.out_scale;
 #pragma unroll
     for (int i = 0; i < WCO; ++i) {
 #pragma unroll
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
             const float4 a4 = *reinterpret_cast<const float4*>(slab + row * SROW + 4 * c4);
             if (ok4 && co < p.Cout) {
                 const float bz = p.bias[co];
-                float4 v = make_float4(a4.x * p.out_scale + bz, a4.y * p.out_scale + bz, a4.z * p.out_scale + bz, a4.w * p.out_scale + bz);
+                float4 v = make_float4(a4.x * osc + bz, a4.y * osc + bz, a4.z * osc + bz, a4.w * osc + bz);
                 const size_t o = base4 + (size_t)co * HW;
                 if (p.res) {
                     const float4 rr = *reinterpret_cast<const float4*>(p.res + o);
@@ -253,6 +255,7 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a) {
     k.zeros = conv_zero_page();
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv5: cannot allocate the zero page"};
     k.out_scale = 1.0f / a.w16_scale;
+    k.out_scale_dev = a.out_scale_dev;
     k.range_ctr = a.range_ctr;
     k.eprm = a.emit_prm; k.ehi = reinterpret_cast<_Float16*>(a.emit_hi); k.elo = reinterpret_cast<_Float16*>(a.emit_lo);
     k.eC8 = 2 * k.n_chunks;

@@ -53,6 +53,7 @@ struct Conv6K {
     float* partial;
     const float* zeros;
     float out_scale;
+    const float* out_scale_dev;            // optional device scalar multiplied into out_scale (dgrad: undoes the run-time scaling of dY)
     float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
 };
 
@@ -348,6 +349,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     float* tr = reinterpret_cast<float*>(smem6) + wave * (32 * TS);
     const int q4 = lane & 15, rsub = lane >> 4;
     float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
+    const float osc = p.out_scale_dev ? p.out_scale * p.out_scale_dev[0] : p.out_scale;
     const bool do_stat = p.stat != nullptr && p.ksplit == 1;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -388,7 +390,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
-                tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[q * 2 + jj][r] * p.out_scale;
+                tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[q * 2 + jj][r] * osc;
         // wave-private slab: program order + the compiler's lgkmcnt waits are all the synchronisation needed
         const int slot = trem * GPI + (q % GPI);
 #pragma unroll
@@ -528,6 +530,7 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, Pendi
     k.C8 = 2 * k.n_chunks_total;          // act.hip pads the blocked tensor to whole 16-channel chunks
     k.partial = a.partial; k.ksplit = 1; k.chunks_per_split = 0;
     k.out_scale = 1.0f / a.w16_scale;
+    k.out_scale_dev = a.out_scale_dev;
     k.zeros = conv_zero_page();
     if (!k.zeros) return Status{DPIR_ERR_NOMEM, "conv6: cannot allocate the zero page"};
     const int tw = geo == 0 ? 32 : (geo == 1 ? 16 : 8), th = geo == 0 ? 8 : (geo == 1 ? 16 : 8), ti = geo == 2 ? 4 : 1;

@@ -28,7 +28,8 @@ struct Workspace {
 
 struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3;
                void* w16 = nullptr; float w16_scale = 1.f;      // operand-split f16 copy (precision modes 1, 2): conv6 layout for 3x3, conv5 layout for 1x1
-               float* wT = nullptr; int coutpT = 0; };          // grad mode: the dgrad operand [coutP16][taps flipped][cinP64] (unet_bwd.hip)
+               float* wT = nullptr; int coutpT = 0;             // grad mode: the dgrad operand [coutP16][taps flipped][cinP64] (unet_bwd.hip)
+               void* w16T = nullptr; float w16T_scale = 1.f; }; // grad mode in the f16 precisions: the same operand in conv6 / conv5 split layout
 struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 struct ResW {
     std::string name;

@@ -16,6 +16,8 @@ struct GnBwdArgs {
     float* ga = nullptr; float* gb = nullptr; int acc_a = 0, acc_b = 0;
 };
 Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B);
+// scal[0] = s (power of two, max|x| * s in [512, 1024)), scal[1] = 1 / s, prm[0 .. n_prm) = {0, s, 0, 0}; part: scratch of 512 floats
+Status launch_grad_scale(hipStream_t s, const float* x, size_t total, float* part, float* scal, float4* prm, int n_prm);
 Status launch_accum_adj(hipStream_t s, const float* src, int Cs, int c0, float* dst, int Cd, int mode, int B, int Hs, int Ws, bool acc);
 Status launch_attention_bwd(hipStream_t s, const float* qkv, const float* dAtt, float* dqkv, float* P, float* dP, int B, int C, int T);
 

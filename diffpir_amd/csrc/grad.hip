@@ -131,6 +131,52 @@ Status launch_accum_adj(hipStream_t s, const float* src, int Cs, int c0, float* 
     return Status{};
 }
 
+// f16 dgrad (unet_bwd.hip): gradients span many orders of magnitude, the f16 operand split does not -- dY is brought to
+// max|dY| * s in [512, 1024) with a power of two s before the split (exactly what the loader does to the weights) and the convolution
+// epilogue multiplies by 1 / s.  Stage 1: per-workgroup max; stage 2: s, 1 / s and the uniform {0, s, 0, 0} table act_split / conv5 read.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t total, float* part) {
+    float m = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+__global__ __launch_bounds__(256) void grad_scale_kernel(const float* part, int nparts, float* scal, float4* prm, int n_prm) {
+    __shared__ float sh;
+    float m = 0.f;
+    for (int i = threadIdx.x; i < nparts; i += 256) m = fmaxf(m, part[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    __shared__ float red[4];
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        float sc = 1.0f;
+        if (mx > 0.f && mx < 3.0e38f) {
+            int ex = (int)floorf(log2f(1024.0f / mx));
+            ex = ex < -100 ? -100 : (ex > 100 ? 100 : ex);
+            sc = exp2f((float)ex);
+            while (mx * sc >= 1024.0f) sc *= 0.5f;
+        }
+        scal[0] = sc; scal[1] = 1.0f / sc;
+        sh = sc;
+    }
+    __syncthreads();
+    const float sc = sh;
+    for (int i = threadIdx.x; i < n_prm; i += 256) prm[i] = make_float4(0.f, sc, 0.f, 0.f);
+}
+Status launch_grad_scale(hipStream_t s, const float* x, size_t total, float* part, float* scal, float4* prm, int n_prm) {
+    const int nparts = 512;
+    hipLaunchKernelGGL(absmax_kernel, dim3(nparts), dim3(256), 0, s, x, total, part);
+    hipLaunchKernelGGL(grad_scale_kernel, dim3(1), dim3(256), 0, s, part, nparts, scal, prm, n_prm);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
 // ---------------------------------------------------------------------------------------------------------------- attention
 // Batched fp32 GEMM for the attention backward (sizes 64 x T x T and T x T x 64, T <= 1024: < 0.5 % of a backward pass):
 //   C[b] (M x N, ldc) = alpha * opA(A[b]) * opB(B[b]);  TA: A is stored K x M (lda), else M x K;  TB: B is stored N x K (ldb), else K x N.

@@ -92,6 +92,21 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
                     pt[((size_t)co * taps + t) * coutT + ci] = w[((size_t)co * cin + ci) * taps + (taps - 1 - t)];
         out->coutpT = coutT;
         DPIR_TRY(upload(e, pt.data(), pt.size(), &out->wT));
+        if (e->precision >= 1 && (ks == 3 || ks == 1)) {
+            // the same operand for the f16 kernels: OIHW of the transposed, flipped filter -> conv6 / conv5 packing
+            std::vector<float> wt((size_t)cin * cout * taps);
+            for (int co = 0; co < cout; ++co)
+                for (int ci = 0; ci < cin; ++ci)
+                    for (int t = 0; t < taps; ++t)
+                        wt[((size_t)ci * cout + co) * taps + t] = w[((size_t)co * cin + ci) * taps + (taps - 1 - t)];
+            std::vector<uint16_t> w16t;
+            out->w16T_scale = ks == 3 ? pack_weights_conv6(wt.data(), cin, cout, w16t) : pack_weights_f16x3_1x1(wt.data(), cin, cout, w16t);
+            void* pp = nullptr;
+            if (hipMalloc(&pp, w16t.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for the split dgrad weights failed"};
+            e->net.allocs.push_back(pp);
+            DPIR_HIP(hipMemcpy(pp, w16t.data(), w16t.size() * 2, hipMemcpyHostToDevice));
+            out->w16T = pp;
+        }
     }
     if (e->precision >= 1 && (ks == 3 || ks == 1)) {
         std::vector<uint16_t> w16;

@@ -5,13 +5,16 @@
 //   ResBlock (unet.py:236-256):   dout -> [skip: identity / resampled identity / 1x1 dgrad] + conv2 dgrad -> GN2+FiLM+SiLU backward
 //                                 -> conv1 dgrad -> (resampling adjoint) GN1+SiLU backward -> gradient of the (concat) input
 //   AttentionBlock (:299-305):    dout -> residual + proj_out dgrad -> QKV attention backward -> qkv dgrad -> GroupNorm backward
-// A convolution's dgrad is the FORWARD fp32 MFMA kernel (conv2.hip / conv.hip) on the transposed, spatially flipped weight pack
-// built at load time; GroupNorm / SiLU / attention / resampling adjoints are in grad.hip.  A tensor with several consumers (block
-// inputs, skip connections) has one gradient buffer: the first contribution writes, later ones accumulate, in tape order --
-// deterministic.  fp32 throughout, whichever arithmetic mode ran the forward.
+// A convolution's dgrad is a FORWARD convolution kernel on the transposed, spatially flipped weight pack built at load time: in the
+// f16 precisions conv6 / conv5 (operand-split MFMA; dY is scaled by a run-time power of two before the split because gradients span
+// many orders of magnitude, the epilogue undoes it), in f32 mode -- and for shapes those kernels do not tile -- conv2 / conv.
+// GroupNorm / SiLU / attention / resampling adjoints are in grad.hip (fp32, fp64 reductions).  A tensor with several consumers
+// (block inputs, skip connections) has one gradient buffer: the first contribution writes, later ones accumulate, in tape order --
+// deterministic.
 #include "engine.h"
 #include "grad.h"
 #include <unordered_map>
+#include <stdlib.h>
 
 namespace dpir {
 namespace {
@@ -36,6 +39,48 @@ struct Bwd {
     // dX [B, cin, H, W] = dgrad of cw applied to dY [B, cout, H, W]
     Status dgrad(const ConvW& cw, const float* dY, float* dX, int H, int W) {
         if (!cw.wT) return Status{DPIR_ERR_STATE, "gradient mode was not enabled before dpir_load_unet (dpir_enable_grad)"};
+        static const bool f16_env = !(getenv("DPIR_DGRAD_F32") && atoi(getenv("DPIR_DGRAD_F32")) != 0);      // A/B switch (tools/, tests)
+        const bool x1 = e->precision == 2;
+        const bool use6 = f16_env && cw.w16T && cw.ks == 3 && conv6_supported(H, W);
+        const bool use5 = f16_env && cw.w16T && cw.ks == 1 && conv5_supported(B, cw.cin, H, W);
+        if (use6 || use5) {
+            // f16 operand-split dgrad on the forward's MFMA kernels.  Gradients span many orders of magnitude: dY is scaled by a run-time
+            // power of two (max|dY| s in [512, 1024)) before the split and the epilogue multiplies by 1 / s (grad.hip launch_grad_scale).
+            const int C = cw.cout;
+            float *part = nullptr, *scal = nullptr; float4* prm = nullptr;
+            DPIR_TRY(ws.getT("bwd#absmax", (size_t)512, &part));
+            DPIR_TRY(ws.getT("bwd#scal", (size_t)4, &scal));
+            DPIR_TRY(ws.getT("bwd#sprm", (size_t)B * 2048, &prm));
+            if (C > 2048) return invalid("dgrad: more than 2048 channels");
+            {
+                ProfScope ps(&e->prof, PC_ELEM);
+                DPIR_TRY(launch_grad_scale(s, dY, (size_t)B * C * H * W, part, scal, prm, B * C));
+            }
+            if (use5) {
+                Conv5Args a5;
+                a5.src = CatSrc{dY, C, nullptr, 0}; a5.prm = prm; a5.w16 = cw.w16T; a5.w16_scale = cw.w16T_scale;
+                a5.bias = zeros; a5.out = dX; a5.res = nullptr; a5.B = B; a5.Cout = cw.cin; a5.H = H; a5.W = W;
+                a5.range_ctr = e->range_ctr; a5.x1 = x1; a5.out_scale_dev = scal + 1;
+                ProfScope ps(&e->prof, PC_CONV1);
+                return launch_conv5(s, a5);
+            }
+            const int C8 = 2 * ((C + 15) / 16);
+            const size_t plane = (size_t)B * C8 * H * W * 16;
+            if (plane >= ((size_t)1 << 32)) return invalid("dgrad: split plane exceeds the 4 GiB buffer-descriptor range; reduce the batch");
+            char* s16 = nullptr;
+            DPIR_TRY(ws.getT("act#s16", 2 * plane, &s16));
+            {
+                ProfScope ps(&e->prof, PC_ELEM);
+                DPIR_TRY(launch_act_split(s, CatSrc{dY, C, nullptr, 0}, prm, 0, B, H, W, s16, x1 ? nullptr : s16 + plane, e->range_ctr));
+            }
+            Conv6Args a6;
+            a6.x1 = x1; a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = cw.w16T; a6.w16_scale = cw.w16T_scale;
+            a6.bias = zeros; a6.out = dX; a6.res = nullptr; a6.res_mode = 0;
+            a6.B = B; a6.Cin = C; a6.Cout = cw.cin; a6.H = H; a6.W = W;
+            a6.partial = partial; a6.partial_capacity = partial_cap; a6.out_scale_dev = scal + 1;
+            ProfScope ps(&e->prof, PC_CONV3);
+            return launch_conv6(s, a6);
+        }
         ConvArgs a;
         a.src.a = dY; a.src.ca = cw.cout; a.src.Hs = H; a.src.Ws = W; a.src.mode = 0; a.src.prm = nullptr;
         a.w = cw.wT; a.bias = zeros; a.out = dX; a.res = nullptr;
