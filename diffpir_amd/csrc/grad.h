@@ -7,7 +7,7 @@ namespace dpir {
 
 // GroupNorm (+FiLM) + SiLU backward for one normalisation site.  x: the (virtual concat) source at Hs x Ws; prm / stats: the
 // forward's per-(image, channel) {mean, a, b, act} table and per-(image, group) {mean, rstd}; dA: gradient w.r.t. the activated,
-// resampled convolution input [B, C, Ho, Wo] (mode as in act.hip); sums: scratch [B * 32] double2.
+// resampled convolution input [B, C, Ho, Wo] (mode as in act.hip); sums: scratch [B * 32 * gn_bwd_parts()] double2.
 // Output: gradient w.r.t. x, written (acc = 0) or accumulated into ga (channels < ca) and gb (the rest).
 struct GnBwdArgs {
     CatSrc x; const float4* prm = nullptr; const float2* stats = nullptr;
@@ -15,6 +15,7 @@ struct GnBwdArgs {
     double2* sums = nullptr;
     float* ga = nullptr; float* gb = nullptr; int acc_a = 0, acc_b = 0;
 };
+int gn_bwd_parts(int C, int Hs, int Ws);
 Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B);
 // scal[0] = s (power of two, max|x| * s in [512, 1024)), scal[1] = 1 / s, prm[0 .. n_prm) = {0, s, 0, 0}; part: scratch of 512 floats
 Status launch_grad_scale(hipStream_t s, const float* x, size_t total, float* part, float* scal, float4* prm, int n_prm);

@@ -44,23 +44,48 @@ __device__ __forceinline__ float gn_G(float xv, float dAs, float4 m, float rstd,
     return du * m.y;
 }
 
-// pass 1: one workgroup per (image, group): fp64 {sum G, sum G x_hat}
-__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p) {
+// pass 1: grid (B * 32, NS): workgroup (n, g, part) sums a contiguous share of the group's elements -> fp64 {sum G, sum G x_hat}
+// partials [B * 32][NS]; pass 2 folds the NS partials of its group in index order.  (One workgroup per group left 256 workgroups with
+// 262 144 elements each at 256^2: hundreds of microseconds per GroupNorm site.)
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p, int NS) {
     const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
+    const int part = blockIdx.y;
     const int C = p.x.ca + p.x.cb, cg = C >> 5;
     const int HWs = p.Hs * p.Ws;
     const int Ho = p.mode == 1 ? p.Hs * 2 : (p.mode == 2 ? p.Hs >> 1 : p.Hs), Wo = p.mode == 1 ? p.Ws * 2 : (p.mode == 2 ? p.Ws >> 1 : p.Ws);
     const float rstd = p.stats[blockIdx.x].y;
+    const long long total = (long long)cg * HWs;
+    const long long per = ((total + NS - 1) / NS + 3) & ~3ll;           // multiple of 4: float4 runs never straddle two workgroups
+    const long long lo = (long long)part * per, hi = lo + per < total ? lo + per : total;
     double S1 = 0.0, S2 = 0.0;
-    for (int k = 0; k < cg; ++k) {
-        const int c = g * cg + k;
-        const float* xp = c < p.x.ca ? p.x.a + ((size_t)n * p.x.ca + c) * HWs : p.x.b + ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
-        const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
-        const float4 m = p.prm[(size_t)n * C + c];
-        for (int i = threadIdx.x; i < HWs; i += 256) {
+    const bool vec = p.mode == 0 && (HWs & 3) == 0;
+    if (vec) {
+        for (long long e4 = lo / 4 + threadIdx.x; e4 * 4 < hi; e4 += 256) {
+            const long long e = e4 * 4;
+            const int k = (int)(e / HWs), i = (int)(e - (long long)k * HWs);
+            const int c = g * cg + k;
+            const float* xp = c < p.x.ca ? p.x.a + ((size_t)n * p.x.ca + c) * HWs : p.x.b + ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
+            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
+            const float4 dv = *reinterpret_cast<const float4*>(p.dA + ((size_t)n * C + c) * HWs + i);
+            const float4 m = p.prm[(size_t)n * C + c];
+            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                float xh;
+                const float G = gn_G(xs[u], ds[u], m, rstd, &xh);
+                S1 += (double)G;
+                S2 += (double)G * (double)xh;
+            }
+        }
+    } else {
+        for (long long e = lo + threadIdx.x; e < hi; e += 256) {
+            const int k = (int)(e / HWs), i = (int)(e - (long long)k * HWs);
+            const int c = g * cg + k;
+            const float* xp = c < p.x.ca ? p.x.a + ((size_t)n * p.x.ca + c) * HWs : p.x.b + ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
+            const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
             const int y = i / p.Ws, x = i - y * p.Ws;
             float xh;
-            const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), m, rstd, &xh);
+            const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), p.prm[(size_t)n * C + c], rstd, &xh);
             S1 += (double)G;
             S2 += (double)G * (double)xh;
         }
@@ -71,12 +96,12 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p) {
     if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = S1; red[1][threadIdx.x >> 6] = S2; }
     __syncthreads();
     if (threadIdx.x == 0)
-        p.sums[blockIdx.x] = make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
+        p.sums[(size_t)blockIdx.x * NS + part] = make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
 }
 
 // pass 2: grid (B * C, ceil(HWs / 256)): dx written (acc == 0) or accumulated (acc != 0) into the gradient of the source tensor
 // the channel belongs to (the two halves of a virtual concat have their own gradient buffers)
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p) {
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) {
     const int C = p.x.ca + p.x.cb, cg = C >> 5;
     const int n = blockIdx.x / C, c = blockIdx.x - n * C;
     const int HWs = p.Hs * p.Ws;
@@ -85,9 +110,10 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p) {
     const int Ho = p.mode == 1 ? p.Hs * 2 : (p.mode == 2 ? p.Hs >> 1 : p.Hs), Wo = p.mode == 1 ? p.Ws * 2 : (p.mode == 2 ? p.Ws >> 1 : p.Ws);
     const int g = c / cg;
     const float rstd = p.stats[n * 32 + g].y;
-    const double2 s = p.sums[n * 32 + g];
+    double s1 = 0.0, s2 = 0.0;
+    for (int q = 0; q < NS; ++q) { const double2 t = p.sums[(size_t)(n * 32 + g) * NS + q]; s1 += t.x; s2 += t.y; }     // fixed order
     const double cnt = (double)cg * HWs;
-    const float m1 = (float)(s.x / cnt), m2 = (float)(s.y / cnt);
+    const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
     const bool in_a = c < p.x.ca;
     const size_t off = in_a ? ((size_t)n * p.x.ca + c) * HWs + i : ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs + i;
     const float xv = in_a ? p.x.a[off] : p.x.b[off];
@@ -101,12 +127,20 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p) {
     dst[off] = acc ? dst[off] + dx : dx;
 }
 
+// partial sums per (image, group): ~8192 elements per workgroup, at most 64
+int gn_bwd_parts(int C, int Hs, int Ws) {
+    const long long total = (long long)(C / 32) * Hs * Ws;
+    long long ns = (total + 8191) / 8192;
+    return (int)(ns < 1 ? 1 : (ns > 64 ? 64 : ns));
+}
+
 Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B) {
     const int C = a.x.ca + a.x.cb;
     if (C % 32 || !a.prm || !a.stats || !a.sums || !a.dA || !a.ga || (a.x.cb && !a.gb)) return invalid("gn_bwd: bad arguments");
     if (a.mode == 2 && ((a.Hs | a.Ws) & 1)) return invalid("gn_bwd: pooled source must be even");
-    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * 32), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 255) / 256), dim3(256), 0, s, a);
+    const int NS = gn_bwd_parts(C, a.Hs, a.Ws);
+    hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * 32, NS), dim3(256), 0, s, a, NS);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 255) / 256), dim3(256), 0, s, a, NS);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -93,7 +93,7 @@ struct Bwd {
                   bool acc_b) {
         GnBwdArgs g;
         g.x = x; g.prm = prm; g.stats = st; g.dA = dA; g.mode = mode; g.Hs = Hs; g.Ws = Ws;
-        DPIR_TRY(ws.getT("bwd#sums", (size_t)B * 32, &g.sums));
+        DPIR_TRY(ws.getT("bwd#sums", (size_t)B * 32 * 64, &g.sums));
         g.ga = ga; g.gb = gb; g.acc_a = acc_a ? 1 : 0; g.acc_b = acc_b ? 1 : 0;
         ProfScope ps(&e->prof, PC_ELEM);
         return launch_gn_bwd(s, g, B);
