@@ -99,32 +99,57 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p, int NS)
         p.sums[(size_t)blockIdx.x * NS + part] = make_double2((red[0][0] + red[0][1]) + (red[0][2] + red[0][3]), (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]));
 }
 
-// pass 2: grid (B * C, ceil(HWs / 256)): dx written (acc == 0) or accumulated (acc != 0) into the gradient of the source tensor
-// the channel belongs to (the two halves of a virtual concat have their own gradient buffers)
+// pass 2: grid (B * C, ceil(HWs / 1024)): one channel plane per blockIdx.x, 4 consecutive pixels per thread (float4 when the plane
+// allows it); dx written (acc == 0) or accumulated (acc != 0) into the gradient of the source tensor the channel belongs to (the two
+// halves of a virtual concat have their own gradient buffers).  The NS partial sums of the group are folded ONCE per workgroup, in
+// index order (first version: every thread re-read all of them -- 24 ms of a 60 ms backward pass).
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) {
     const int C = p.x.ca + p.x.cb, cg = C >> 5;
     const int n = blockIdx.x / C, c = blockIdx.x - n * C;
     const int HWs = p.Hs * p.Ws;
-    const int i = blockIdx.y * 256 + threadIdx.x;
-    if (i >= HWs) return;
     const int Ho = p.mode == 1 ? p.Hs * 2 : (p.mode == 2 ? p.Hs >> 1 : p.Hs), Wo = p.mode == 1 ? p.Ws * 2 : (p.mode == 2 ? p.Ws >> 1 : p.Ws);
     const int g = c / cg;
+    __shared__ double2 part_sh[64];
+    __shared__ float m_sh[2];
+    if ((int)threadIdx.x < NS) part_sh[threadIdx.x] = p.sums[(size_t)(n * 32 + g) * NS + threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double s1 = 0.0, s2 = 0.0;
+        for (int q = 0; q < NS; ++q) { s1 += part_sh[q].x; s2 += part_sh[q].y; }
+        const double cnt = (double)cg * HWs;
+        m_sh[0] = (float)(s1 / cnt); m_sh[1] = (float)(s2 / cnt);
+    }
+    __syncthreads();
+    const float m1 = m_sh[0], m2 = m_sh[1];
     const float rstd = p.stats[n * 32 + g].y;
-    double s1 = 0.0, s2 = 0.0;
-    for (int q = 0; q < NS; ++q) { const double2 t = p.sums[(size_t)(n * 32 + g) * NS + q]; s1 += t.x; s2 += t.y; }     // fixed order
-    const double cnt = (double)cg * HWs;
-    const float m1 = (float)(s1 / cnt), m2 = (float)(s2 / cnt);
+    const float4 m = p.prm[(size_t)n * C + c];
     const bool in_a = c < p.x.ca;
-    const size_t off = in_a ? ((size_t)n * p.x.ca + c) * HWs + i : ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs + i;
-    const float xv = in_a ? p.x.a[off] : p.x.b[off];
-    const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
-    const int y = i / p.Ws, x = i - y * p.Ws;
-    float xh;
-    const float G = gn_G(xv, adj_read(dp, p.mode, y, x, p.Ws), p.prm[(size_t)n * C + c], rstd, &xh);
-    const float dx = G - m1 - xh * m2;
-    float* dst = in_a ? p.ga : p.gb;
+    const size_t base = in_a ? ((size_t)n * p.x.ca + c) * HWs : ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
+    const float* xp = (in_a ? p.x.a : p.x.b) + base;
+    float* dst = (in_a ? p.ga : p.gb) + base;
     const int acc = in_a ? p.acc_a : p.acc_b;
-    dst[off] = acc ? dst[off] + dx : dx;
+    const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
+    const int i0 = (blockIdx.y * 256 + threadIdx.x) * 4;
+    if (i0 >= HWs) return;
+    if (p.mode == 0 && (HWs & 3) == 0) {
+        const float4 xv = *reinterpret_cast<const float4*>(xp + i0);
+        const float4 dv = *reinterpret_cast<const float4*>(dp + i0);
+        float4 o = acc ? *reinterpret_cast<const float4*>(dst + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
+        float xh, G;
+        G = gn_G(xv.x, dv.x, m, rstd, &xh); o.x += G - m1 - xh * m2;
+        G = gn_G(xv.y, dv.y, m, rstd, &xh); o.y += G - m1 - xh * m2;
+        G = gn_G(xv.z, dv.z, m, rstd, &xh); o.z += G - m1 - xh * m2;
+        G = gn_G(xv.w, dv.w, m, rstd, &xh); o.w += G - m1 - xh * m2;
+        *reinterpret_cast<float4*>(dst + i0) = o;
+        return;
+    }
+    for (int i = i0; i < i0 + 4 && i < HWs; ++i) {
+        const int y = i / p.Ws, x = i - y * p.Ws;
+        float xh;
+        const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), m, rstd, &xh);
+        const float dx = G - m1 - xh * m2;
+        dst[i] = acc ? dst[i] + dx : dx;
+    }
 }
 
 // partial sums per (image, group): ~8192 elements per workgroup, at most 64
@@ -140,7 +165,7 @@ Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B) {
     if (a.mode == 2 && ((a.Hs | a.Ws) & 1)) return invalid("gn_bwd: pooled source must be even");
     const int NS = gn_bwd_parts(C, a.Hs, a.Ws);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * 32, NS), dim3(256), 0, s, a, NS);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 255) / 256), dim3(256), 0, s, a, NS);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 1023) / 1024), dim3(256), 0, s, a, NS);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -150,6 +175,16 @@ Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B) {
 __global__ __launch_bounds__(256) void accum_adj_kernel(const float* src, int Cs, int c0, float* dst, int Cd, int mode, int Hs, int Ws, int acc) {
     const int n = blockIdx.x / Cd, c = blockIdx.x - n * Cd;
     const int HWs = Hs * Ws;
+    if (mode == 0 && (HWs & 3) == 0) {                 // plain copy / add of a channel plane: 4 pixels per thread, one pass per 1024
+        const float* sp4 = src + ((size_t)n * Cs + c0 + c) * HWs;
+        float* dp4 = dst + ((size_t)n * Cd + c) * HWs;
+        for (int i4 = (blockIdx.y * 256 + threadIdx.x) * 4; i4 < HWs; i4 += gridDim.y * 1024) {
+            float4 v = *reinterpret_cast<const float4*>(sp4 + i4);
+            if (acc) { const float4 o = *reinterpret_cast<const float4*>(dp4 + i4); v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *reinterpret_cast<float4*>(dp4 + i4) = v;
+        }
+        return;
+    }
     const int i = blockIdx.y * 256 + threadIdx.x;
     if (i >= HWs) return;
     const int Ho = mode == 1 ? Hs * 2 : (mode == 2 ? Hs >> 1 : Hs), Wo = mode == 1 ? Ws * 2 : (mode == 2 ? Ws >> 1 : Ws);
@@ -160,7 +195,8 @@ __global__ __launch_bounds__(256) void accum_adj_kernel(const float* src, int Cs
     dst[o] = acc ? dst[o] + v : v;
 }
 Status launch_accum_adj(hipStream_t s, const float* src, int Cs, int c0, float* dst, int Cd, int mode, int B, int Hs, int Ws, bool acc) {
-    hipLaunchKernelGGL(accum_adj_kernel, dim3(B * Cd, (Hs * Ws + 255) / 256), dim3(256), 0, s, src, Cs, c0, dst, Cd, mode, Hs, Ws, acc ? 1 : 0);
+    const int per_block = (mode == 0 && ((Hs * Ws) & 3) == 0) ? 1024 : 256;
+    hipLaunchKernelGGL(accum_adj_kernel, dim3(B * Cd, (Hs * Ws + per_block - 1) / per_block), dim3(256), 0, s, src, Cs, c0, dst, Cd, mode, Hs, Ws, acc ? 1 : 0);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -170,7 +206,13 @@ Status launch_accum_adj(hipStream_t s, const float* src, int Cs, int c0, float* 
 // epilogue multiplies by 1 / s.  Stage 1: per-workgroup max; stage 2: s, 1 / s and the uniform {0, s, 0, 0} table act_split / conv5 read.
 __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t total, float* part) {
     float m = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
+    const size_t n4 = total >> 2;                       // tensors here are [B, C, H, W] with H * W % 4 == 0 or tiny
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    }
+    for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
     __shared__ float red[4];
