@@ -72,7 +72,10 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;                                  // [N]
     float2* xch = sm2 + N;                              // [SLOTS][RJ*(R+1)]
-    float2* zbuf = xch + SLOTS * RJ * (R + 1);          // [SLOTS][N+4]  natural-order Z of each slot (also the load staging)
+    // [SLOTS][N+4] natural-order Z of each slot (also the load staging).  ALIASED with the exchange area: staging is dead once the
+    // two-pass layout has been gathered into registers, the exchange area is dead when fft_two_pass returns (each hand-over is a
+    // __syncthreads) -- 19 -> 10.7 KiB per workgroup at N = 256, 8 -> 14 resident workgroups per CU (pays at B >= 64)
+    float2* zbuf = xch;
     if (sp) pm = sp->tau;
     for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
@@ -84,22 +87,37 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
     {
         const size_t row0 = (size_t)blockIdx.x * SLOTS * 2;
         constexpr int V4 = N / 4;
-        for (int i = threadIdx.x; i < 2 * SLOTS * V4; i += THREADS) {
-            int r = i / V4, c4 = i - r * V4;
-            size_t row = row0 + r;
-            float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < total_rows) {
-                q = *reinterpret_cast<const float4*>(x + row * N + c4 * 4);
+        // ALL loads of the workgroup's rows are issued before the first one is consumed (a load -> LDS-store loop body is a chain of
+        // dependent memory round trips: 8 per thread at N = 256)
+        constexpr int NL = (2 * SLOTS * V4 + THREADS - 1) / THREADS;
+        float4 q[NL], e4[NL];
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = threadIdx.x + j * THREADS;
+            const int r = i / V4, c4 = i - r * V4;
+            const size_t row = row0 + r;
+            q[j] = make_float4(0.f, 0.f, 0.f, 0.f); e4[j] = q[j];
+            if (i < 2 * SLOTS * V4 && row < total_rows) {
+                q[j] = *reinterpret_cast<const float4*>(x + row * N + c4 * 4);
                 if (fu.eps6) {
-#pragma clang fp contract(off)
                     const size_t plane = row / N, n = plane / 3, c = plane - n * 3;
-                    const float4 e4 = *reinterpret_cast<const float4*>(fu.eps6 + ((n * fu.out_ch + c) * N + (row - plane * N)) * N + c4 * 4);
-                    const float c1 = sp->c1, c2 = sp->c2;
-                    q.x = fminf(fmaxf(c1 * q.x - c2 * e4.x, -1.0f), 1.0f); q.y = fminf(fmaxf(c1 * q.y - c2 * e4.y, -1.0f), 1.0f);
-                    q.z = fminf(fmaxf(c1 * q.z - c2 * e4.z, -1.0f), 1.0f); q.w = fminf(fmaxf(c1 * q.w - c2 * e4.w, -1.0f), 1.0f);
+                    e4[j] = *reinterpret_cast<const float4*>(fu.eps6 + ((n * fu.out_ch + c) * N + (row - plane * N)) * N + c4 * 4);
                 }
             }
-            *reinterpret_cast<float4*>(stage + r * (N + 4) + c4 * 4) = q;
+        }
+#pragma unroll
+        for (int j = 0; j < NL; ++j) {
+            const int i = threadIdx.x + j * THREADS;
+            const int r = i / V4, c4 = i - r * V4;
+            if (i >= 2 * SLOTS * V4) continue;
+            float4 qq = q[j];
+            if (fu.eps6 && row0 + r < total_rows) {
+#pragma clang fp contract(off)
+                const float c1 = sp->c1, c2 = sp->c2;
+                qq.x = fminf(fmaxf(c1 * qq.x - c2 * e4[j].x, -1.0f), 1.0f); qq.y = fminf(fmaxf(c1 * qq.y - c2 * e4[j].y, -1.0f), 1.0f);
+                qq.z = fminf(fmaxf(c1 * qq.z - c2 * e4[j].z, -1.0f), 1.0f); qq.w = fminf(fmaxf(c1 * qq.w - c2 * e4[j].w, -1.0f), 1.0f);
+            }
+            *reinterpret_cast<float4*>(stage + r * (N + 4) + c4 * 4) = qq;
         }
     }
     __syncthreads();
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
     extern __shared__ __attribute__((aligned(16))) float2 sm2[];
     float2* twN = sm2;
     float2* xch = sm2 + N;
-    float2* zbuf = xch + SLOTS * RJ * (R + 1);
+    float2* zbuf = xch;                                 // aliased with the exchange area (see rfft_rows_kernel)
     for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
@@ -157,10 +175,23 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
     const bool va = ra < total_rows, vb = rb < total_rows;
     float2* z = zbuf + slot * (N + 4);
     // Hermitian re-packing: Z[k] = A[k] + i B[k], Z[N-k] = conj(A[k]) + i conj(B[k])
-    for (int k = t; k <= N / 2; k += R) {
-        const int ks = col_slot ? col_slot[k] : k;          // where column k is stored (sf > 1: permuted)
-        float2 A = va ? in[ra * WP + ks] : make_float2(0.f, 0.f);
-        float2 Bv = vb ? in[rb * WP + ks] : make_float2(0.f, 0.f);
+    constexpr int NK = (N / 2 + 1 + R - 1) / R;               // all loads in flight before the first LDS write (see rfft_rows_kernel)
+    float2 Av[NK], Bw[NK];
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = t + j * R;
+        Av[j] = make_float2(0.f, 0.f); Bw[j] = Av[j];
+        if (k <= N / 2) {
+            const int ks = col_slot ? col_slot[k] : k;      // where column k is stored (sf > 1: permuted)
+            if (va) Av[j] = in[ra * WP + ks];
+            if (vb) Bw[j] = in[rb * WP + ks];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NK; ++j) {
+        const int k = t + j * R;
+        if (k > N / 2) continue;
+        const float2 A = Av[j], Bv = Bw[j];
         z[k] = make_float2(A.x - Bv.y, A.y + Bv.x);
         if (k > 0 && k < N / 2) z[N - k] = make_float2(A.x + Bv.y, -A.y + Bv.x);
     }
@@ -403,7 +434,10 @@ constexpr int ROW_THREADS = 64;    // small workgroups: at B = 16 the whole prox
 // 16 columns per strip for both sizes: a strip row is one full 128-byte line (8 columns = half lines cost ~2x the requests)
 template <int R> struct ColCfg { static constexpr int THREADS = 16 * R; };
 template <int R, int RJ>
-static size_t rows_lds() { return (size_t)(R * RJ + (ROW_THREADS / R) * RJ * (R + 1) + (ROW_THREADS / R) * (R * RJ + 4)) * sizeof(float2); }
+static size_t rows_lds() {      // twiddles + max(exchange area, natural-order / staging area): the two are aliased
+    constexpr size_t xch = (size_t)(ROW_THREADS / R) * RJ * (R + 1), zb = (size_t)(ROW_THREADS / R) * (R * RJ + 4);
+    return (R * RJ + (xch > zb ? xch : zb)) * sizeof(float2);
+}
 template <int R, int RJ>
 static size_t cols_lds() { return (size_t)(R * RJ + (ColCfg<R>::THREADS / R) * (RJ * (R + 1) + 1)) * sizeof(float2); }
 

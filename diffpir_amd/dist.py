@@ -64,8 +64,17 @@ def init(collective: str = "rccl"):
 def attach(engine):
     """Bind this rank's engine to the group: creates the RCCL communicator on the engine's device (rccl mode)."""
     if _state["mode"] == "rccl-pending":
-        init_rccl(engine, _state["rank"], _state["world"])
-        _state.update(mode="rccl", engine=engine)
+        try:
+            init_rccl(engine, _state["rank"], _state["world"])
+            _state.update(mode="rccl", engine=engine)
+        except Exception as ex:                      # loud, not silent: the run continues on the rendezvous fallback
+            import sys
+            import torch.distributed as dist
+            print(f"[diffpir_amd.dist] rank {_state['rank']}: RCCL through the C ABI failed ({ex}); falling back to torch.distributed/nccl",
+                  file=sys.stderr, flush=True)
+            if not dist.is_initialized():
+                dist.init_process_group("nccl", rank=_state["rank"], world_size=_state["world"])
+            _state.update(mode="torch", engine=engine)
     elif _state["mode"] == "torch":
         _state["engine"] = engine
 
@@ -141,7 +150,7 @@ def init_rccl(engine, rank: int, world: int, port: int = None):
                 c.close()
             srv.close()
     else:
-        for attempt in range(600):
+        for attempt in range(6000):            # rank 0 may still be packing weights (up to minutes for the 2 GB topologies)
             try:
                 c = socket.create_connection((addr, port), timeout=5)
                 break
