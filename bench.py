@@ -350,7 +350,7 @@ def main():
         eg.sync()
         td = time.perf_counter() - ta
         dps = {"what": "generate_mode DPS_y0 (main_ddpir.py:370-373, 434-438), FFHQ topology, x4 SISR 64^2 -> 256^2: per NFE one UNet forward "
-                       f"({args.precision}), p_sample, residual norm, Resizer^T and one UNet input-gradient pass (fp32 MFMA dgrad); eager launches",
+                       f"({args.precision}), p_sample, residual norm, Resizer^T and one UNet input-gradient pass (dgrad on the same MFMA kernels as the forward); eager launches",
                "batch": Bd, "nfe": nfe_d, "ms_per_nfe": round(td / (nfe_d - 1) * 1e3, 2),
                "images_per_s_at_100_nfe": round(Bd / (td / (nfe_d - 1) * 100), 4), "finite": bool(np.isfinite(od.numpy()).all())}
         eg.close()
