@@ -186,7 +186,8 @@ struct Conv5Args {
     const float4* emit_prm = nullptr; void* emit_hi = nullptr; void* emit_lo = nullptr;
     const float* out_scale_dev = nullptr;      // optional device scalar folded into the output scale (dgrad)
 };
-bool conv5_supported(int B, int Cout, int H, int W);
+constexpr int kConv5EmitMaxC = 384;            // channels of the GroupNorm table the plane-emitting variant stages in LDS
+bool conv5_supported(int B, int Cout, int H, int W, bool has_prm = false);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);
 float pack_weights_f16x3_1x1(const float* w_oi, int cout, int cin, std::vector<uint16_t>& out);
 // part[n*C+c] = fp64 {sum, sum of squares} of one channel plane of the (virtual-concat) input

@@ -33,6 +33,7 @@
 //
 // Tile geometries (256 pixels): 8 rows x 32 columns (W >= 32), 16 x 16 (W >= 16), 4 images x 8 x 8 (W >= 8).
 #include "common.h"
+#include "lds_dma.h"
 #include <math.h>
 #include <type_traits>
 #include <vector>
@@ -57,22 +58,6 @@ struct Conv6K {
     float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
 };
 
-// LDS-DMA through a buffer descriptor: `buffer_load_dwordx4 v_off, s[rsrc], s_off offen lds`.  The descriptor (4 SGPRs) and
-// the scalar offset carry everything wave-uniform, so a DMA instruction costs ONE live VGPR (the per-lane byte offset) and
-// no vector address arithmetic; a per-lane offset >= num_records is out of range and the hardware writes ZEROS for that
-// lane -- which is how the halo positions outside the image (and the padding of the last piece) are produced.
-#define BLDS6(rsrc, dst, voff, soff) \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds((rsrc), (__attribute__((address_space(3))) void*)(dst), 16, (voff), (soff), 0, 0)
-constexpr unsigned kOutOfRange = 0xFFFFFFFFu;
-// Descriptor from values that ARE wave-uniform but that the compiler cannot always prove so: without the readfirstlane it
-// wraps every buffer operation in a "waterfall" loop (v_readfirstlane x4, compare, s_and_saveexec, op, loop).
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t rsrc_uniform(const void* ptr, unsigned bytes) {
-    const unsigned long long a = reinterpret_cast<unsigned long long>(ptr);
-    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((unsigned long long)hi << 32) | lo), 0,
-                                             __builtin_amdgcn_readfirstlane(bytes), 0x00020000);
-}
-
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
     if constexpr (I < N) {
@@ -91,13 +76,11 @@ template <> struct Geo6<0> { static constexpr int LTW = 5, LTH = 3, TI = 1; };  
 template <> struct Geo6<1> { static constexpr int LTW = 4, LTH = 4, TI = 1; };   // 16 x 16
 template <> struct Geo6<2> { static constexpr int LTW = 3, LTH = 3, TI = 4; };   // 4 images x 8 x 8
 
-// s_waitcnt with only the vector-memory counter constrained (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14])
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    static_assert(N >= 0 && N < 64, "vmcnt range");
-    __builtin_amdgcn_s_waitcnt((N & 15) | (7 << 4) | (15 << 8) | ((N >> 4) << 14));
-    asm volatile("" ::: "memory");
-}
+// A/B switch of the chunk-boundary barrier (lds_dma.h barrier_lds_only against __syncthreads with its vmcnt(0))
+#ifndef DPIR_C6_LDS_BARRIER
+#define DPIR_C6_LDS_BARRIER 1
+#endif
+[[maybe_unused]] constexpr bool LDS_BARRIER = DPIR_C6_LDS_BARRIER != 0;
 
 // DMA instructions issued by the group of tap i of a chunk (i < 0: tap i + 9 of the previous chunk, always a MORE body):
 // [one activation piece of the next chunk if i < nact] + [the two weight pieces of tap i + d]
@@ -323,7 +306,7 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
                 // weights of the next chunk's tap 0 (followed by the groups of taps 11-D .. 8) -- an EXPLICIT wait: the compiler
                 // does not know that a ds_read depends on an LDS-DMA and may leave vmcnt out of the barrier's wait.
                 wait_vmcnt<NPL + NPL * (TAPS - NACT)>();
-                __syncthreads();
+                if (LDS_BARRIER) barrier_lds_only(); else __syncthreads();
                 wait_vmcnt<c6_wait_n(true, NACT, D, TAPS - 1, NPL)>();
                 read_a((rbase + TAPS) % R, 1);
                 read_b(cur ^ 1, 0, 0, 0);
@@ -344,71 +327,131 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
     // ---- epilogue: per wave, four passes of 32 co x 64 px through a private LDS slab (transposition to float4 rows of 4
     // consecutive pixels), bias / residual / GroupNorm partial sums fused.  The other workgroup on this CU keeps the matrix
     // pipe busy meanwhile.
+    // STRAIGHT-LINE code (r3).  The first version predicated every residual load and every store with a branch and loaded the bias
+    // inside the store loop; the compiler's waitcnt pass gives up counting across those joins and put `s_waitcnt vmcnt(0)` behind
+    // every single residual load and in front of every store: 8 serialised load latencies + 8 store round trips per pass, 64 per
+    // tile, as long as the tile's whole MFMA phase.  Here every access goes through a buffer descriptor with the predicate folded
+    // into the offset (out of range: loads return 0, stores are dropped), the bias is loaded once, and the residual rows of pass
+    // q + 1 are requested BEFORE the stores of pass q, so that waiting for them never waits for a store.
     __syncthreads();                                         // all waves are done with the operand buffers
     constexpr int TS = 68;                                   // slab row stride in floats (16-byte aligned, bank-skewed)
     float* tr = reinterpret_cast<float*>(smem6) + wave * (32 * TS);
     const int q4 = lane & 15, rsub = lane >> 4;
-    float* dst = p.ksplit > 1 ? p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW) : p.out;
+    const bool single = p.ksplit == 1;
+    float* dst = single ? p.out : p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW);
     const float osc = p.out_scale_dev ? p.out_scale * p.out_scale_dev[0] : p.out_scale;
-    const bool do_stat = p.stat != nullptr && p.ksplit == 1;
+    const bool do_stat = p.stat != nullptr && single;
+    const int res_mode = (single && p.res) ? p.res_mode : -1;
+    const size_t img0 = (size_t)n0 * p.Cout;                 // first (image, channel) plane of the tile
+    const size_t res_plane = res_mode == 1 ? (size_t)(HW >> 2) : (res_mode == 2 ? (size_t)HW * 4 : (size_t)HW);
+    // per-lane offsets are relative to the tile's first image and stay far below 4 GiB; the descriptors only exist for the
+    // out-of-range semantics, so their size is "everything" (enabled) or 0 (that operand does not exist: zeros / no store)
+    // (the descriptors are rebuilt from scalars right where they are used: one that lives across the branches below ends up in
+    // vector registers and every buffer operation in a readfirstlane "waterfall" loop)
+    float* const out_base = dst + img0 * HW;
+    const float* const res_base = res_mode >= 0 ? p.res + img0 * res_plane : p.bias;
+    const unsigned res_bytes = res_mode >= 0 ? 0xFFFFFFFFu : 0u;
+    const void* const stat_base = do_stat ? (const void*)(p.stat + img0 * p.stat_slots) : (const void*)p.bias;
+    const unsigned stat_bytes = do_stat ? 0xFFFFFFFFu : 0u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    auto f4 = [](u32x4 v) { return make_float4(as_f32(v.x), as_f32(v.y), as_f32(v.z), as_f32(v.w)); };
+
+    float bv[8];
+    const __amdgpu_buffer_rsrc_t r_bias = rsrc_uniform(p.bias, single ? (unsigned)p.Cout * 4u : 0u);
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
+    for (int it = 0; it < 8; ++it) bv[it] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(r_bias, (unsigned)(co0 + it * 4 + rsub) * 4u, 0, 0));
+
+    // geometry of pass q for this lane: 4 consecutive pixels of one row
+    struct PassGeo { int ti, y, x; bool pok; unsigned pix; };
+    auto geo = [&](int q) {
         const int pp = q * 64 + q4 * 4;
-        const int px = pp & (TW - 1);
-        const int py = (pp >> G::LTW) & (TH - 1);
-        const int ti = pp >> (G::LTW + G::LTH);
-        const int n = n0 + ti, y = ty0 + py, x = tx0 + px;
-        const bool pok = n < p.B && y < p.H && x < p.W;
-        const size_t pix = (size_t)y * p.W + x;
-        // residual values first (all three forms reduced to one float4 per channel row here): their latency overlaps the
-        // transposition, and the store loop below is branch-free
-        float4 rv[8];
-        const bool with_res = p.ksplit == 1 && p.res != nullptr;
+        PassGeo g;
+        g.ti = pp >> (G::LTW + G::LTH);
+        g.y = ty0 + ((pp >> G::LTW) & (TH - 1));
+        g.x = tx0 + (pp & (TW - 1));
+        g.pok = n0 + g.ti < p.B && g.y < p.H && g.x < p.W;
+        g.pix = (unsigned)(g.y * p.W + g.x);
+        return g;
+    };
+    // residual rows of pass q (all three forms reduced to one float4 per channel row)
+    auto load_res = [&](int q, float4 (&rv)[8]) __attribute__((always_inline)) {
+        const PassGeo g = geo(q);
+        const __amdgpu_buffer_rsrc_t r_res = rsrc_uniform(res_base, res_bytes);
+        if (res_mode <= 0) {                               // same shape as the output (or none: zero-sized descriptor)
 #pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int co = co0 + it * 4 + rsub;
-            rv[it] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (with_res && pok && co < p.Cout) {
-                const size_t plane = (size_t)n * p.Cout + co;
-                if (p.res_mode == 0) {
-                    rv[it] = *reinterpret_cast<const float4*>(p.res + plane * HW + pix);
-                } else if (p.res_mode == 1) {              // residual at half resolution, nearest up-sampling (unet.py:107)
-                    const int Hr = p.H >> 1, Wr = p.W >> 1;
-                    const float2 r2 = *reinterpret_cast<const float2*>(p.res + plane * (size_t)(Hr * Wr) + (size_t)(y >> 1) * Wr + (x >> 1));
-                    rv[it] = make_float4(r2.x, r2.x, r2.y, r2.y);
-                } else {                                   // residual at double resolution, 2x2 average pooling (unet.py:136)
-                    const int Wr = p.W * 2;
-                    const float* rp = p.res + plane * (4 * (size_t)HW) + (size_t)(2 * y) * Wr + 2 * x;
-                    const float4 a0 = *reinterpret_cast<const float4*>(rp), a1 = *reinterpret_cast<const float4*>(rp + 4);
-                    const float4 b0 = *reinterpret_cast<const float4*>(rp + Wr), b1 = *reinterpret_cast<const float4*>(rp + Wr + 4);
-                    rv[it] = make_float4(((a0.x + a0.y) + (b0.x + b0.y)) * 0.25f, ((a0.z + a0.w) + (b0.z + b0.w)) * 0.25f,
-                                         ((a1.x + a1.y) + (b1.x + b1.y)) * 0.25f, ((a1.z + a1.w) + (b1.z + b1.w)) * 0.25f);
+            for (int it = 0; it < 8; ++it) {
+                const int co = co0 + it * 4 + rsub;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * (unsigned)HW + g.pix) * 4u : kOutOfRange;
+                rv[it] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
+            }
+        } else if (res_mode == 1) {                        // residual at half resolution, nearest up-sampling (unet.py:107)
+            const unsigned Wr = (unsigned)(p.W >> 1), HWr = (unsigned)(HW >> 2);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int co = co0 + it * 4 + rsub;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(g.y >> 1) * Wr + (unsigned)(g.x >> 1)) * 4u : kOutOfRange;
+                const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(r_res, off, 0, 0);
+                const float a = as_f32(r2.x), b = as_f32(r2.y);
+                rv[it] = make_float4(a, a, b, b);
+            }
+        } else {                                           // residual at double resolution, 2x2 average pooling (unet.py:136)
+            const unsigned Wr = (unsigned)p.W * 2u, HWr = (unsigned)HW * 4u;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {                  // two channel rows (8 loads) at a time: register pressure
+                float4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int co = co0 + (h * 2 + i2) * 4 + rsub;
+                    const bool ok = g.pok && co < p.Cout;
+                    const unsigned off = ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(2 * g.y) * Wr + (unsigned)(2 * g.x)) * 4u;
+                    a0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off : kOutOfRange, 0, 0));
+                    a1[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + 16u : kOutOfRange, 0, 0));
+                    b0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + Wr * 4u : kOutOfRange, 0, 0));
+                    b1[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + Wr * 4u + 16u : kOutOfRange, 0, 0));
                 }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+                    rv[h * 2 + i2] = make_float4(((a0[i2].x + a0[i2].y) + (b0[i2].x + b0[i2].y)) * 0.25f, ((a0[i2].z + a0[i2].w) + (b0[i2].z + b0[i2].w)) * 0.25f,
+                                                 ((a1[i2].x + a1[i2].y) + (b1[i2].x + b1[i2].y)) * 0.25f, ((a1[i2].z + a1[i2].w) + (b1[i2].z + b1[i2].w)) * 0.25f);
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
+    };
+
+    // (one straight-line instance of the passes per residual form would let the waitcnt pass count exactly -- the join of the three
+    // forms makes the first store of a pass wait for the previous pass's stores -- but it costs > 30 spilled registers: not taken)
+    float4 rv[2][8];
+    load_res(0, rv[0]);
+    static_for<0, 4>([&](auto q_c) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_c)::value;
+        const PassGeo g = geo(q);
 #pragma unroll
         for (int jj = 0; jj < 2; ++jj)
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[q * 2 + jj][r] * osc;
         // wave-private slab: program order + the compiler's lgkmcnt waits are all the synchronisation needed
+        if (q + 1 < 4) load_res(q + 1, rv[(q + 1) & 1]);   // requested before this pass's stores
         const int slot = trem * GPI + (q % GPI);
+        const __amdgpu_buffer_rsrc_t r_out = rsrc_uniform(out_base, 0xFFFFFFFFu);
+        const __amdgpu_buffer_rsrc_t r_stat = rsrc_uniform(stat_base, stat_bytes);
 #pragma unroll
         for (int it = 0; it < 8; ++it) {
             const int co_l = it * 4 + rsub;
             const int co = co0 + co_l;
-            const bool cok = co < p.Cout;
+            const bool ok = g.pok && co < p.Cout;
             float4 v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
-            if (!(cok && pok)) v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (cok && pok) {
-                const size_t plane = (size_t)n * p.Cout + co;
-                if (p.ksplit == 1) {
-                    const float bv = p.bias[co];
-                    v.x += bv; v.y += bv; v.z += bv; v.w += bv;
-                    v.x = rv[it].x + v.x; v.y = rv[it].y + v.y; v.z = rv[it].z + v.z; v.w = rv[it].w + v.w;
-                }
-                *reinterpret_cast<float4*>(dst + plane * HW + pix) = v;
+            if (single) {
+                v.x += bv[it]; v.y += bv[it]; v.z += bv[it]; v.w += bv[it];
+                const float4 r4 = rv[q & 1][it];
+                v.x = r4.x + v.x; v.y = r4.y + v.y; v.z = r4.z + v.z; v.w = r4.w + v.w;
             }
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            const unsigned plane_l = (unsigned)(g.ti * p.Cout + co);
+            u32x4 sv;
+            sv.x = as_u32(v.x); sv.y = as_u32(v.y); sv.z = as_u32(v.z); sv.w = as_u32(v.w);
+            __builtin_amdgcn_raw_buffer_store_b128(sv, r_out, ok ? (plane_l * (unsigned)HW + g.pix) * 4u : kOutOfRange, 0, 0);
             if (do_stat) {
                 float s1 = (v.x + v.y) + (v.z + v.w);
                 float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -418,10 +461,13 @@ __global__ __launch_bounds__(256, 2) void conv6_mfma_kernel(Conv6K p) {
                 s1 += dpp_row_shr6<0x114>(s1); s2 += dpp_row_shr6<0x114>(s2);
                 s1 += dpp_row_shr6<0x118>(s1); s2 += dpp_row_shr6<0x118>(s2);
                 // a 64-pixel group belongs to ONE image (GPI groups per image and tile); groups wholly outside the image store 0
-                if (q4 == 15 && cok && n < p.B) p.stat[((size_t)n * p.Cout + co) * p.stat_slots + slot] = make_float2(s1, s2);
+                u32x2 st;
+                st.x = as_u32(s1); st.y = as_u32(s2);
+                const bool wr = q4 == 15 && co < p.Cout && n0 + g.ti < p.B;
+                __builtin_amdgcn_raw_buffer_store_b64(st, r_stat, wr ? (plane_l * (unsigned)p.stat_slots + (unsigned)slot) * 8u : kOutOfRange, 0, 0);
             }
         }
-    }
+    });
 #endif
 }
 

@@ -395,7 +395,8 @@ struct Fwd {
     Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
         const bool x1 = e->precision == 2;        // f16x1: single-product mode, hi halves only
         // an unfinished split-K output is finished before anything but the fused prologue reads it (or reuses the slab buffer)
-        const bool use5 = cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo);   // no slab buffer
+        const bool use5 = cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo, prm != nullptr) &&
+                          !(prm && in.C() % 16);   // no slab buffer
         if (pending.partial && (is_pending(in.a) || is_pending(in.b) || is_pending(res) || !use5)) DPIR_TRY(resolve());
         if (cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo)) {
             // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
@@ -478,7 +479,7 @@ struct Fwd {
         const int Cin = in.C();
         const size_t eplane = (size_t)B * (2 * ((Cin + 15) / 16)) * Ho * Wo * 16;
         if ((emit_skip == 2 || (emit_skip == 1 && r.cout <= 128)) && r.has_skip && r.mode == 0 && r.conv1.w16 && r.skip.w16 && conv6_supported(Ho, Wo) && conv5_supported(B, r.cout, Ho, Wo) &&
-            Cin % 16 == 0 && Cin <= 1024 && (Ho * Wo) % 256 == 0 && eplane < ((size_t)1 << 32) && !(fuse_small && gn_act_small_supported(Cin, in.H, in.W, 0))) {
+            Cin % 16 == 0 && Cin <= kConv5EmitMaxC && (Ho * Wo) % 256 == 0 && eplane < ((size_t)1 << 32) && !(fuse_small && gn_act_small_supported(Cin, in.H, in.W, 0))) {
             const bool x1 = e->precision == 2;
             float4* prm1 = nullptr;
             DPIR_TRY(resolve());
