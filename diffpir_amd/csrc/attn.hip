@@ -37,10 +37,15 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* qkv, float*
     const int tq = t0 + l31;
     const bool q_ok = tq < T;
 
-    // Q as B operand: lane (c = 2kk+half, t = l31)
+    // Q as B operand: lane (c = 2kk+half, t = l31).  The loads are unconditional (clamped index, value selected afterwards): as
+    // `q_ok ? load : 0` every one of the 32 loads sat in its own predicated block with an `s_waitcnt vmcnt(0)` behind it -- 32
+    // serialised HBM latencies before the first MFMA (tools/isa_audit.py, "after_load").
     float qreg[HC / 2];
+    const int tqc = q_ok ? tq : T - 1;
 #pragma unroll
-    for (int kk = 0; kk < HC / 2; ++kk) qreg[kk] = q_ok ? qb[(size_t)(2 * kk + half) * T + tq] * scale : 0.f;
+    for (int kk = 0; kk < HC / 2; ++kk) qreg[kk] = qb[(size_t)(2 * kk + half) * T + tqc];
+#pragma unroll
+    for (int kk = 0; kk < HC / 2; ++kk) qreg[kk] = q_ok ? qreg[kk] * scale : 0.f;
 
     floatx16 o[2];
 #pragma unroll
@@ -51,9 +56,11 @@ __global__ __launch_bounds__(256) void attention_kernel(const float* qkv, float*
         __syncthreads();
         for (int i = tid; i < HC * KT; i += nthr) {
             int c = i >> 5, s = i & 31;
-            bool ok = s0 + s < T;
-            lds_k[c * KT + s] = ok ? kb[(size_t)c * T + s0 + s] * scale : 0.f;
-            lds_v[c * VS + s] = ok ? vb[(size_t)c * T + s0 + s] : 0.f;
+            const bool ok = s0 + s < T;
+            const int sc = ok ? s0 + s : T - 1;                  // unconditional loads, as above
+            const float kv = kb[(size_t)c * T + sc], vv = vb[(size_t)c * T + sc];
+            lds_k[c * KT + s] = ok ? kv * scale : 0.f;
+            lds_v[c * VS + s] = ok ? vv : 0.f;
         }
         __syncthreads();
         floatx16 st;
