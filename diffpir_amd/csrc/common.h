@@ -165,6 +165,7 @@ struct Conv6Args {
     double2* stat_plane = nullptr; // optional [B][Cout] fp64 {sum, sum of squares}, written by the split-K combine
     bool x1 = false;               // single-product mode (f16x1): hi planes / hi weight halves only
     const float* out_scale_dev = nullptr;      // optional device scalar folded into the output scale (dgrad, unet_bwd.hip)
+    int force_kernel = 0;          // tests only: 6 = conv6 even where conv7 applies, 7 = conv7 or an error; 0 = launch_conv6 decides
 };
 bool conv6_supported(int H, int W);
 int conv6_stat_slots(int H, int W);

@@ -20,6 +20,21 @@ static int fail(dpir_engine* e, const Status& s) {
             return fail((e), Status{DPIR_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_h)}); \
     } while (0)
 
+// elements whose bit patterns differ (out[0]) and their largest absolute difference as ordered uint bits (out[1])
+__global__ void dbg_bitdiff_kernel(const float* a, const float* b, size_t n, unsigned long long* out) {
+    unsigned long long cnt = 0; unsigned mx = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const float x = a[i], y = b[i];
+        if (__builtin_bit_cast(unsigned, x) != __builtin_bit_cast(unsigned, y)) {
+            ++cnt;
+            const float d = fabsf(x - y);
+            const unsigned u = d == d ? __builtin_bit_cast(unsigned, d) : 0x7fc00000u;
+            mx = u > mx ? u : mx;
+        }
+    }
+    if (cnt) { atomicAdd(&out[0], cnt); atomicMax(&out[1], (unsigned long long)mx); }
+}
+
 extern "C" {
 // Times one convolution shape in isolation (synthetic operands already on the device).  mode bits: 0 = exact-fp32 kernels,
 // 1 = f16x3 (conv6 for 3x3 incl. its act_split pre-pass, conv5 for 1x1), 2 = f16x3 without the pre-pass (planes prepared once).
@@ -89,6 +104,82 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
     float ms = 0; API_HIP(e, hipEventElapsedTime(&ms, e0, e1));
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_out = ms / iters;
+    return DPIR_OK;
+}
+
+// conv7 against conv6 on the same split planes and weight pack (include/diffpir_debug.h): outputs and fused GroupNorm sums must
+// agree bit for bit; then both kernels are timed back to back.  res_mode: -1 none, 0 same shape, 1 half resolution, 2 double resolution.
+int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int iters,
+                           double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out) {
+    if (!e || !ms6_out || !ms7_out || !mismatches_out || !maxdiff_out || iters <= 0 || res_mode < -1 || res_mode > 2) return DPIR_ERR_INVALID;
+    (void)hipSetDevice(e->device);
+    const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W;
+    const size_t nres = res_mode == 1 ? no / 4 : (res_mode == 2 ? no * 4 : no);
+    const int slots = conv6_stat_slots(H, W);
+    const size_t nst = (size_t)B * Cout * slots;
+    float *x = nullptr, *bias = nullptr, *o6 = nullptr, *o7 = nullptr, *res = nullptr;
+    float2 *st6 = nullptr, *st7 = nullptr;
+    unsigned long long* cmp = nullptr;
+    API_TRY(e, e->ws.getT("c7#x", nx, &x));
+    API_TRY(e, e->ws.getT("c7#b", (size_t)round_up(Cout, 64), &bias));
+    API_TRY(e, e->ws.getT("c7#o6", no, &o6));
+    API_TRY(e, e->ws.getT("c7#o7", no, &o7));
+    API_TRY(e, e->ws.getT("c7#res", nres, &res));
+    API_TRY(e, e->ws.getT("c7#st6", nst, &st6));
+    API_TRY(e, e->ws.getT("c7#st7", nst, &st7));
+    API_TRY(e, e->ws.getT("c7#cmp", (size_t)2, &cmp));
+    API_TRY(e, launch_randn(e->stream, x, 11, 1, 0, 1, nx));
+    API_TRY(e, launch_randn(e->stream, bias, 12, 1, 0, 1, (size_t)round_up(Cout, 64)));
+    API_TRY(e, launch_randn(e->stream, res, 13, 1, 0, 1, nres));
+    std::vector<float> hw((size_t)Cout * Cin * 9);
+    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
+    std::vector<uint16_t> w16v;
+    const float w16_scale = pack_weights_conv6(hw.data(), Cout, Cin, w16v);
+    void* wp = nullptr;
+    API_TRY(e, e->ws.get("c7#w16", w16v.size() * 2, &wp));
+    API_HIP(e, hipMemcpy(wp, w16v.data(), w16v.size() * 2, hipMemcpyHostToDevice));
+    const int C8 = 2 * ((Cin + 15) / 16);
+    const size_t plane = (size_t)B * C8 * H * W * 16;
+    char* s16 = nullptr;
+    API_TRY(e, e->ws.getT("c7#s16", 2 * plane, &s16));
+    API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, nullptr, 0, B, H, W, s16, s16 + plane));
+    Conv6Args a6;
+    a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = wp; a6.w16_scale = w16_scale; a6.bias = bias;
+    a6.B = B; a6.Cin = Cin; a6.Cout = Cout; a6.H = H; a6.W = W;
+    if (res_mode >= 0) { a6.res = res; a6.res_mode = res_mode; }
+    Conv6Args a7 = a6;
+    a6.out = o6; a6.stat = st6; a6.force_kernel = 6;
+    a7.out = o7; a7.stat = st7; a7.force_kernel = 7;
+    API_HIP(e, hipMemsetAsync(o6, 0xFF, no * 4, e->stream));
+    API_HIP(e, hipMemsetAsync(o7, 0x7F, no * 4, e->stream));
+    API_HIP(e, hipMemsetAsync(st6, 0xFF, nst * 8, e->stream));
+    API_HIP(e, hipMemsetAsync(st7, 0x7F, nst * 8, e->stream));
+    API_HIP(e, hipMemsetAsync(cmp, 0, 16, e->stream));
+    int k6 = 0, k7 = 0;
+    API_TRY(e, launch_conv6(e->stream, a6, &k6));
+    API_TRY(e, launch_conv6(e->stream, a7, &k7));
+    if (k6 != 1 || k7 != 1) return fail(e, Status{DPIR_ERR_INVALID, "conv7 check: the shape does not take the fused-statistics whole-K route"});
+    hipLaunchKernelGGL(dbg_bitdiff_kernel, dim3(2048), dim3(256), 0, e->stream, o6, o7, no, cmp);
+    hipLaunchKernelGGL(dbg_bitdiff_kernel, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<const float*>(st6), reinterpret_cast<const float*>(st7), nst * 2, cmp);
+    unsigned long long h[2] = {0, 0};
+    API_HIP(e, hipMemcpyAsync(h, cmp, 16, hipMemcpyDeviceToHost, e->stream));
+    API_HIP(e, hipStreamSynchronize(e->stream));
+    *mismatches_out = h[0];
+    const unsigned mb = (unsigned)h[1];
+    *maxdiff_out = __builtin_bit_cast(float, mb);
+    hipEvent_t e0, e1, e2;
+    API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1)); API_HIP(e, hipEventCreate(&e2));
+    for (int i = 0; i < 3; ++i) { API_TRY(e, launch_conv6(e->stream, a6)); API_TRY(e, launch_conv6(e->stream, a7)); }
+    API_HIP(e, hipEventRecord(e0, e->stream));
+    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv6(e->stream, a6));
+    API_HIP(e, hipEventRecord(e1, e->stream));
+    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv6(e->stream, a7));
+    API_HIP(e, hipEventRecord(e2, e->stream));
+    API_HIP(e, hipEventSynchronize(e2));
+    float m6 = 0, m7 = 0;
+    API_HIP(e, hipEventElapsedTime(&m6, e0, e1)); API_HIP(e, hipEventElapsedTime(&m7, e1, e2));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
+    *ms6_out = m6 / iters; *ms7_out = m7 / iters;
     return DPIR_OK;
 }
 

@@ -20,10 +20,11 @@ int dpir_debug_victim_alu(dpir_engine* e, int mode, int blocks, int iters_in_ker
  * threads whose two identical computations disagreed. */
 int dpir_debug_victim_fft_pk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
 int dpir_debug_victim_fft_nopk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
-/* conv7 prototype (csrc/conv7_proto.hip: 64 co x 128 px per wave, weights straight into registers) against conv6 on the same split
- * planes and weight pack: *mismatches_out = output elements whose bits differ (expected 0: same MFMA order per accumulator),
- * *maxdiff_out their largest absolute difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
-int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int iters,
+/* conv7 (csrc/conv7.hip: 64 co x 128 px per wave, weights straight into registers) against conv6 on the same split planes and weight
+ * pack, with fused GroupNorm sums and the residual form res_mode (-1 none, 0 same shape, 1 half resolution, 2 double resolution):
+ * *mismatches_out = output + statistics elements whose bits differ (expected 0: same MFMA order per accumulator), *maxdiff_out their
+ * largest absolute difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
+int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int iters,
                            double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out);
 #ifdef __cplusplus
 }
