@@ -70,7 +70,7 @@ def test_hot_kernels_carry_no_compiler_inserted_serialisation():
     ia = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ia)
     kernels = ia.disassemble(SO)
-    seen = {"conv5_mfma_kernel": 0, "conv6_mfma_kernel": 0, "attention_kernel": 0}
+    seen = {"conv5_mfma_kernel": 0, "conv6_mfma_kernel": 0, "conv7_mfma_kernel": 0, "attention_kernel": 0}
     for sym, ins in kernels.items():
         r = ia.audit(ins)
         if "conv5_mfma_kernel" in sym:
@@ -81,7 +81,11 @@ def test_hot_kernels_carry_no_compiler_inserted_serialisation():
             seen["conv6_mfma_kernel"] += 1
             # one legitimate wait: the last chunk's operands, right before its first read
             assert r["scratch"] == 0 and r["vmcnt0_before_ds_read"] <= 1 and r["vmcnt0_after_load"] <= 1, (sym, r)
+        elif "conv7_mfma_kernel" in sym:
+            seen["conv7_mfma_kernel"] += 1
+            # weights go straight into registers: only the activation patch is DMA'd (6 pieces in the prologue + 6 in the loop body)
+            assert r["scratch"] == 0 and r["vmcnt0_before_ds_read"] == 0 and r["vmcnt0_after_load"] == 0 and r["lds_dma"] == 12, (sym, r)
         elif "attention_kernel" in sym:
             seen["attention_kernel"] += 1
             assert r["vmcnt0_after_load"] == 0 and r["scratch"] == 0, (sym, r)
-    assert seen["conv5_mfma_kernel"] == 6 and seen["conv6_mfma_kernel"] == 6 and seen["attention_kernel"] == 1, seen
+    assert seen == {"conv5_mfma_kernel": 6, "conv6_mfma_kernel": 6, "conv7_mfma_kernel": 1, "attention_kernel": 1}, seen
