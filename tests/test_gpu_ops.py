@@ -170,3 +170,17 @@ def test_device_randn_statistics_and_shard_invariance(engine):
     c = engine.empty((B, C_, H, W))
     engine._check(engine.lib.dpir_randn(engine.h, c.ptr, 123, 6, 0, B, C_, H, W))
     assert np.abs(np.corrcoef(c.numpy().ravel(), v.ravel())[0, 1]) < 0.01
+
+
+def test_conv7_is_bit_identical_to_conv6(engine):
+    """csrc/conv7.hip (64 co x 128 px per wave, weights straight into registers) takes over conv6's geometry-0 whole-K launches on the
+    strength of producing the SAME bits: outputs and fused GroupNorm sums, for every residual form (tools/conv7_check.py, through the
+    test-only library).  Three small cases here; the tool's default list covers the benched layer shapes."""
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("conv7_check", os.path.join(root, "tools", "conv7_check.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    cases = [(2, 128, 128, 64, 64, (-1, 0, 1, 2)), (3, 48, 128, 40, 72, (0, 2)), (1, 6, 128, 96, 96, (-1,))]
+    assert mod.run(iters=1, cases=cases, engine=engine) == 0
