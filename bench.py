@@ -122,8 +122,9 @@ def conv_roofline(eng, B, H, precision, model_name):
     achieved = fl / (ms * 1e-3) / 1e12
     peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x1": 2500.0}.get(precision, PEAK_F16X3_TFLOPS)
     kern = ("conv2_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32, exact fp32)" if precision == "f32" else
-            "conv6_mfma_kernel<3x3> (3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split*_kernel; "
-            "two workgroups per CU)")
+            "conv6_mfma_kernel<3x3, X1> (one v_mfma_f32_32x32x16_f16 per product, hi planes only; two workgroups per CU)" if precision == "f16x1" else
+            "3x3 class: conv7_mfma_kernel (whole-K launches of the 8x32 geometry) + conv6_mfma_kernel (split-K, 16x16 / 8x8) "
+            "(3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split*_kernel; two workgroups per CU)")
     step_fl = eng.unet_flops(H, H) * B
     tr = PMC_TRAFFIC.get(f"{model_name}_B{B}_{H}_{precision}")
     return {"bound": "mfma", "kernel": kern, "achieved": round(achieved, 3), "peak": round(peak, 1), "unit": "TFLOP/s",
