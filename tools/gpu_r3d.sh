@@ -1,5 +1,8 @@
 #!/bin/bash
-# r3 conv5 / conv6 pipeline fixes: correctness subset, then A/B forward timings against the HEAD build and the __syncthreads variant
+# r3 conv5 / conv6 pipeline fixes: correctness subset, then A/B forward timings against the previous commit's build and the __syncthreads
+# variant.  The two variant libraries are built by hand next to the product library before the call (they are git-ignored):
+#   libdiffpir_hip_base.so        = `git archive <previous commit> diffpir_amd/csrc include | tar -x -C /tmp/base && make -C /tmp/base/diffpir_amd/csrc libdiffpir_hip.so`
+#   libdiffpir_hip_syncthreads.so = the current tree built with CXXFLAGS += -DDPIR_C6_LDS_BARRIER=0
 tag=${1:-r3n}
 out=gpurun_out/$tag
 mkdir -p $out
