@@ -1,0 +1,386 @@
+// conv7x: conv7 (csrc/conv7.hip) generalised to EVERYTHING conv6 does -- the 16 x 16 and 4-image 8 x 8 geometries, split-K partial
+// slabs, f16x1, the run-time output scale of dgrad, idle co-halves (Cout <= 64 in the last block).  TEST-ONLY library for now
+// (libdiffpir_dbg.so): written at the end of round 3 without GPU time left; `dpir_debug_conv7x_check` compares it bit for bit with
+// conv6 on the same operands (outputs, statistics, partial slabs).  Once that check is green on hardware it replaces conv7.hip and
+// conv6.hip goes away.
+#include "common.h"
+#include "lds_dma.h"
+#include "conv6_params.h"
+#include <type_traits>
+
+namespace dpir {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef _Float16 half8 __attribute__((ext_vector_type(8)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for7(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for7<I + 1, N>(f);
+    }
+}
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_row_shr7(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+
+template <int GEO> struct Geo7;
+template <> struct Geo7<0> { static constexpr int LTW = 5, LTH = 3, TI = 1; };   // 8 rows x 32 columns
+template <> struct Geo7<1> { static constexpr int LTW = 4, LTH = 4, TI = 1; };   // 16 x 16
+template <> struct Geo7<2> { static constexpr int LTW = 3, LTH = 3, TI = 4; };   // 4 images x 8 x 8
+
+template <int GEO, bool X1>
+__global__ __launch_bounds__(256, 2) void conv7x_kernel(Conv6K p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    using G = Geo7<GEO>;
+    constexpr int TW = 1 << G::LTW, TH = 1 << G::LTH, TI = G::TI, LW = TW + 2, LH = TH + 2;
+    constexpr int PATCH = TI * LH * LW;                 // entries per k-half
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;       // one-KiB DMA pieces per plane
+    constexpr int NXT = (NPIECE + 3) / 4;               // per wave and plane
+    constexpr int NPL = X1 ? 1 : 2;                     // operand planes (hi [, lo])
+    constexpr int NACT = NPL * NXT;                     // activation DMA instructions per wave and chunk
+    static_assert(NACT <= 8, "the activation pieces must be older than the weights of taps 7 and 8");
+    constexpr int XB = NPIECE * 1024;
+    constexpr int TAPS = 9;
+    extern __shared__ __attribute__((aligned(16))) char smem7x[];      // [2 buffers][hi|lo][XB]; the epilogue slabs alias it
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int cw = wave & 1, pw = wave >> 1;            // co half (64 channels), pixel half (rows 4 pw .. 4 pw + 3)
+    const int l31 = lane & 31;
+    const int half = lane >> 5;
+
+    int bid = blockIdx.x;
+    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous tiles, as conv6
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
+    const int co_blk = bid % p.n_co_blocks;
+    const int ptile = bid / p.n_co_blocks;
+    const int tiles_per_img = p.tiles_x * p.tiles_y;
+    const int img_grp = ptile / tiles_per_img;
+    const int n0 = img_grp * TI;
+    const int trem = ptile - img_grp * tiles_per_img;
+    const int ch_begin = split * p.chunks_per_split;
+    const int ch_end = min(p.n_chunks_total, ch_begin + p.chunks_per_split);
+    const int co_wave = co_blk * 128 + cw * 64;              // this wave's first output channel
+    const bool wave_live = co_wave < p.Cout;
+    const int ty0 = (trem / p.tiles_x) * TH;
+    const int tx0 = (trem % p.tiles_x) * TW;
+    const int HW = p.H * p.W;
+
+    // ---- activation DMA: identical to conv6 (pieces dealt to the 4 waves, out-of-image positions out of range = zeros)
+    unsigned x_off[NXT];
+#pragma unroll
+    for (int u = 0; u < NXT; ++u) {
+        int piece = wave + u * 4;
+        if (piece > NPIECE - 1) piece = NPIECE - 1;
+        const int f = piece * 64 + lane;
+        const int kg = f / PATCH;
+        const int e = f - kg * PATCH;
+        const int ti = e / (LH * LW);
+        const int rr = e - ti * (LH * LW);
+        const int hy = rr / LW, hx = rr - hy * LW;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        const int n = n0 + ti;
+        const bool ok = kg < 2 && n < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        x_off[u] = ok ? ((unsigned)((n * p.C8 + kg) * HW + gy * p.W + gx) << 4) : kOutOfRange;
+    }
+    const size_t xplane_bytes = (size_t)p.B * p.C8 * HW * 16;
+    auto dma_x = [&](int chunk, int buf, int q) __attribute__((always_inline)) {
+        const int u = X1 ? q : q >> 1, plane = X1 ? 0 : q & 1;
+        int piece = wave + u * 4;
+        if (piece > NPIECE - 1) piece = NPIECE - 1;
+        const size_t coff = (size_t)chunk * 2 * HW * 16;
+        const __amdgpu_buffer_rsrc_t rx = rsrc_uniform((plane ? p.xlo : p.xhi) + coff, (unsigned)(xplane_bytes - coff));
+        BLDS6(rx, smem7x + buf * 2 * XB + plane * XB + piece * 1024, x_off[u], 0);
+    };
+
+    // ---- B fragments: this wave's pixel tiles are 4 pw .. 4 pw + 3 of conv6's eight (tile_off is additive in the wave part)
+    auto tile_off = [](int j) constexpr -> int { return GEO == 0 ? j * LW : (GEO == 1 ? 2 * j * LW : (j >> 1) * (LH * LW) + (j & 1) * 4 * LW); };
+    const int wave_off = GEO == 0 ? 4 * pw * LW : (GEO == 1 ? 8 * pw * LW : 2 * pw * (LH * LW));
+    const int lane_b = (GEO == 0 ? l31 : (GEO == 1 ? (l31 >> 4) * LW + (l31 & 15) : (l31 >> 3) * LW + (l31 & 7))) + half * PATCH + wave_off;
+    const half8* xbase = reinterpret_cast<const half8*>(smem7x) + lane_b;
+
+    // ---- A fragments straight from the weight pack: record (chunk, co_blk, co-tile ct, tap) = 2 KiB [hi | lo], 16 B per lane
+    const unsigned lane16 = (unsigned)lane * 16u;
+    half8 a_h[3][2], a_l[3][2];
+    auto load_a = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
+        const char* base = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * (4 * TAPS * 2048);
+        const __amdgpu_buffer_rsrc_t rw = rsrc_uniform(base, 4 * TAPS * 2048);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const unsigned so = (unsigned)(((2 * cw + i) * TAPS + tap) * 2048);
+            a_h[slot][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, so, 0));
+            if (!X1) a_l[slot][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, so + 1024u, 0));
+        }
+    };
+
+    floatx16 acc[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    half8 b_h[2][2], b_l[2][2];      // two pixel tiles per set, two sets (one in use, one being filled)
+    auto read_b = [&](int buf, int tap, int grp, int set) __attribute__((always_inline)) {      // pixel tiles 2 grp, 2 grp + 1
+        const half8* xh = xbase + buf * (2 * XB / 16);
+        const half8* xl = xh + XB / 16;
+        const int toff = (tap / 3) * LW + (tap % 3);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int o = tile_off(grp * 2 + j) + toff;
+            b_h[set][j] = xh[o];
+            if (!X1) b_l[set][j] = xl[o];
+        }
+    };
+    auto mfma_group = [&](int grp, int set, int slot) __attribute__((always_inline)) {
+        // per accumulator: al * bh, ah * bl, ah * bh -- conv6's order
+        if (!X1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[slot][i], b_h[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_l[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_h[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+    };
+
+    // Waves whose 64 output channels lie beyond Cout only carry their share of the activation DMA and keep the barrier count
+    // (prologue, one per chunk boundary, epilogue): no weights, no MFMAs.
+    if (!wave_live) {
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+        wait_vmcnt<0>();
+        __syncthreads();
+        int it = 0;
+        for (int chunk = ch_begin; chunk + 1 < ch_end; ++chunk, ++it) {
+#pragma unroll
+            for (int q = 0; q < NACT; ++q) dma_x(chunk + 1, (it & 1) ^ 1, q);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        __syncthreads();
+        return;
+    }
+
+    // ---- prologue: first patch, weights of taps 0 and 1
+#pragma unroll
+    for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+    load_a(ch_begin, 0, 0);
+    load_a(ch_begin, 1, 1);
+    wait_vmcnt<0>();
+    __syncthreads();
+    read_b(0, 0, 0, 0);
+
+    // One K chunk: 9 taps x 2 groups of (2 pixel tiles x 2 co-tiles x 3) = 12 MFMAs.  At tap t the weights of tap t + 2 are requested
+    // (ring slot (t + 2) % 3; at taps 7 / 8 those are the next chunk's taps 0 / 1) and, for t < NACT, one activation piece of the next
+    // chunk.  The compiler counts the register loads itself; the activation pieces are older than the weights of taps 7 and 8, so
+    // "at most those 8 loads outstanding" at the chunk boundary proves that they have landed.
+    auto chunk_body = [&](auto more_c, int chunk, int it) __attribute__((always_inline)) {
+        constexpr bool MORE = decltype(more_c)::value;
+        const int cur = it & 1;
+        static_for7<0, TAPS>([&](auto tap_c) __attribute__((always_inline)) {
+            constexpr int tap = decltype(tap_c)::value;
+            constexpr int slot = tap % 3;
+            read_b(cur, tap, 1, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (MORE && tap < NACT) dma_x(chunk + 1, cur ^ 1, tap);
+            if (tap + 2 < TAPS) load_a(chunk, tap + 2, (tap + 2) % 3);
+            else if (MORE) load_a(chunk + 1, tap + 2 - TAPS, (tap + 2) % 3);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(0, 0, slot);
+            __builtin_amdgcn_sched_barrier(0);
+            if (tap + 1 < TAPS) {
+                read_b(cur, tap + 1, 0, 0);
+            } else if (MORE) {
+                wait_vmcnt<4 * NPL>();             // the weights of taps 7 and 8 (the next chunk's 0 and 1) may still be in flight
+                barrier_lds_only();
+                read_b(cur ^ 1, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            mfma_group(1, 1, slot);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    };
+    {
+        int it = 0, chunk = ch_begin;
+        for (; chunk + 1 < ch_end; ++chunk, ++it) chunk_body(std::true_type{}, chunk, it);
+        chunk_body(std::false_type{}, chunk, it);
+    }
+
+    // ---- epilogue: conv6's (straight-line buffer-descriptor code, see there), four passes q = (co-tile i, pixel-tile pair jp) of
+    // 32 co x 64 px: bias, un-scaling, residual in its three forms, GroupNorm partial sums (slot = the 64-pixel group of the tile)
+    __syncthreads();
+    constexpr int TS = 68;
+    constexpr int GPI = (TW * TH) / 64;                      // 64-pixel groups per image inside one tile
+    float* tr = reinterpret_cast<float*>(smem7x) + wave * (32 * TS);
+    const int q4 = lane & 15, rsub = lane >> 4;
+    const bool single = p.ksplit == 1;
+    const float osc = p.out_scale_dev ? p.out_scale * p.out_scale_dev[0] : p.out_scale;
+    const bool do_stat = p.stat != nullptr && single;
+    const int res_mode = (single && p.res) ? p.res_mode : -1;
+    float* const dst = single ? p.out : p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW);
+    const size_t img0 = (size_t)n0 * p.Cout;
+    const size_t res_plane = res_mode == 1 ? (size_t)(HW >> 2) : (res_mode == 2 ? (size_t)HW * 4 : (size_t)HW);
+    float* const out_base = dst + img0 * HW;
+    const float* const res_base = res_mode >= 0 ? p.res + img0 * res_plane : p.bias;
+    const unsigned res_bytes = res_mode >= 0 ? 0xFFFFFFFFu : 0u;
+    const void* const stat_base = do_stat ? (const void*)(p.stat + img0 * p.stat_slots) : (const void*)p.bias;
+    const unsigned stat_bytes = do_stat ? 0xFFFFFFFFu : 0u;
+    typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    auto f4 = [](u32x4 v) { return make_float4(as_f32(v.x), as_f32(v.y), as_f32(v.z), as_f32(v.w)); };
+
+    float bv[2][8];
+    {
+        const __amdgpu_buffer_rsrc_t r_bias = rsrc_uniform(p.bias, single ? (unsigned)p.Cout * 4u : 0u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) bv[i][it] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(r_bias, (unsigned)(co_wave + i * 32 + it * 4 + rsub) * 4u, 0, 0));
+    }
+    struct PassGeo { int ti, y, x; bool pok; unsigned pix; };
+    auto geo = [&](int q) {
+        const int pp = (pw * 2 + (q & 1)) * 64 + q4 * 4;
+        PassGeo g;
+        g.ti = pp >> (G::LTW + G::LTH);
+        g.y = ty0 + ((pp >> G::LTW) & (TH - 1));
+        g.x = tx0 + (pp & (TW - 1));
+        g.pok = n0 + g.ti < p.B && g.y < p.H && g.x < p.W;
+        g.pix = (unsigned)(g.y * p.W + g.x);
+        return g;
+    };
+    auto load_res = [&](int q, float4 (&rv)[8]) __attribute__((always_inline)) {
+        const PassGeo g = geo(q);
+        const int co0 = co_wave + (q >> 1) * 32;
+        const __amdgpu_buffer_rsrc_t r_res = rsrc_uniform(res_base, res_bytes);
+        if (res_mode <= 0) {                               // same shape as the output (or none: zero-sized descriptor)
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int co = co0 + it * 4 + rsub;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * (unsigned)HW + g.pix) * 4u : kOutOfRange;
+                rv[it] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
+            }
+        } else if (res_mode == 1) {                        // residual at half resolution, nearest up-sampling (unet.py:107)
+            const unsigned Wr = (unsigned)(p.W >> 1), HWr = (unsigned)(HW >> 2);
+#pragma unroll
+            for (int it = 0; it < 8; ++it) {
+                const int co = co0 + it * 4 + rsub;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(g.y >> 1) * Wr + (unsigned)(g.x >> 1)) * 4u : kOutOfRange;
+                const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(r_res, off, 0, 0);
+                const float a = as_f32(r2.x), b = as_f32(r2.y);
+                rv[it] = make_float4(a, a, b, b);
+            }
+        } else {                                           // residual at double resolution, 2x2 average pooling (unet.py:136)
+            const unsigned Wr = (unsigned)p.W * 2u, HWr = (unsigned)HW * 4u;
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {                  // two channel rows (8 loads) at a time: register pressure
+                float4 a0[2], a1[2], b0[2], b1[2];
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2) {
+                    const int co = co0 + (h * 2 + i2) * 4 + rsub;
+                    const bool ok = g.pok && co < p.Cout;
+                    const unsigned off = ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(2 * g.y) * Wr + (unsigned)(2 * g.x)) * 4u;
+                    a0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off : kOutOfRange, 0, 0));
+                    a1[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + 16u : kOutOfRange, 0, 0));
+                    b0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + Wr * 4u : kOutOfRange, 0, 0));
+                    b1[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + Wr * 4u + 16u : kOutOfRange, 0, 0));
+                }
+#pragma unroll
+                for (int i2 = 0; i2 < 2; ++i2)
+                    rv[h * 2 + i2] = make_float4(((a0[i2].x + a0[i2].y) + (b0[i2].x + b0[i2].y)) * 0.25f, ((a0[i2].z + a0[i2].w) + (b0[i2].z + b0[i2].w)) * 0.25f,
+                                                 ((a1[i2].x + a1[i2].y) + (b1[i2].x + b1[i2].y)) * 0.25f, ((a1[i2].z + a1[i2].w) + (b1[i2].z + b1[i2].w)) * 0.25f);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    };
+
+    float4 rv[2][8];
+    load_res(0, rv[0]);
+    static_for7<0, 4>([&](auto q_c) __attribute__((always_inline)) {
+        constexpr int q = decltype(q_c)::value;
+        constexpr int i = q >> 1, jp = q & 1;
+        const PassGeo g = geo(q);
+        const int co0 = co_wave + i * 32;
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[i][jp * 2 + jj][r] * osc;
+        if (q + 1 < 4) load_res(q + 1, rv[(q + 1) & 1]);   // requested before this pass's stores
+        const int slot = trem * GPI + ((pw * 2 + jp) % GPI);
+        const __amdgpu_buffer_rsrc_t r_out = rsrc_uniform(out_base, 0xFFFFFFFFu);
+        const __amdgpu_buffer_rsrc_t r_stat = rsrc_uniform(stat_base, stat_bytes);
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int co_l = it * 4 + rsub;
+            const int co = co0 + co_l;
+            const bool ok = g.pok && co < p.Cout;
+            float4 v = *reinterpret_cast<const float4*>(tr + co_l * TS + q4 * 4);
+            {
+                v.x += bv[i][it]; v.y += bv[i][it]; v.z += bv[i][it]; v.w += bv[i][it];
+                const float4 r4 = rv[q & 1][it];
+                v.x = r4.x + v.x; v.y = r4.y + v.y; v.z = r4.z + v.z; v.w = r4.w + v.w;
+            }
+            if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
+            u32x4 sv;
+            sv.x = as_u32(v.x); sv.y = as_u32(v.y); sv.z = as_u32(v.z); sv.w = as_u32(v.w);
+            const unsigned plane_l = (unsigned)(g.ti * p.Cout + co);
+            __builtin_amdgcn_raw_buffer_store_b128(sv, r_out, ok ? (plane_l * (unsigned)HW + g.pix) * 4u : kOutOfRange, 0, 0);
+            if (do_stat) {
+                float s1 = (v.x + v.y) + (v.z + v.w);
+                float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                s1 += dpp_row_shr7<0x111>(s1); s2 += dpp_row_shr7<0x111>(s2);
+                s1 += dpp_row_shr7<0x112>(s1); s2 += dpp_row_shr7<0x112>(s2);
+                s1 += dpp_row_shr7<0x114>(s1); s2 += dpp_row_shr7<0x114>(s2);
+                s1 += dpp_row_shr7<0x118>(s1); s2 += dpp_row_shr7<0x118>(s2);
+                u32x2 st;
+                st.x = as_u32(s1); st.y = as_u32(s2);
+                const bool wr = q4 == 15 && co < p.Cout && n0 + g.ti < p.B;
+                __builtin_amdgcn_raw_buffer_store_b64(st, r_stat, wr ? (plane_l * (unsigned)p.stat_slots + (unsigned)slot) * 8u : kOutOfRange, 0, 0);
+            }
+        }
+    });
+#endif
+}
+
+template <int GEO, bool X1>
+static Status launch7x(hipStream_t s, const Conv6K& k, int blocks) {
+    using G = Geo7<GEO>;
+    constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;
+    constexpr size_t LDS = (size_t)4 * NPIECE * 1024;           // two buffers x (hi, lo); the epilogue slabs (34 KiB) alias them
+    static_assert(LDS >= 4 * 32 * 68 * 4, "epilogue slabs");
+    auto fn = conv7x_kernel<GEO, X1>;
+    static LdsAttrOnce attr_set;
+    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), (int)LDS));
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), LDS, s, k);
+    return Status{};
+}
+
+// k as launch_conv6 fills it (geometry from H, W as conv6_geo); blocks = pixel tiles x co-blocks x ksplit
+Status launch_conv7x(hipStream_t s, const Conv6K& k, int blocks, bool x1) {
+    if ((k.W & 3) || k.W < 8 || k.H < 8) return invalid("conv7x: shape not tiled");
+    const int geo = k.W >= 32 ? 0 : (k.W >= 16 ? 1 : 2);
+    if (x1) {
+        if (geo == 0) return launch7x<0, true>(s, k, blocks);
+        if (geo == 1) return launch7x<1, true>(s, k, blocks);
+        return launch7x<2, true>(s, k, blocks);
+    }
+    if (geo == 0) return launch7x<0, false>(s, k, blocks);
+    if (geo == 1) return launch7x<1, false>(s, k, blocks);
+    return launch7x<2, false>(s, k, blocks);
+}
+
+}  // namespace dpir

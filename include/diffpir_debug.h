@@ -26,6 +26,10 @@ int dpir_debug_victim_fft_nopk(dpir_engine* e, int blocks, int iters_in_kernel, 
  * largest absolute difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
 int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int iters,
                            double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out);
+/* conv7x (csrc/conv7x.hip, test-only: conv7 generalised to every conv6 case) against conv6; x1: f16x1; split: allow split-K (the
+ * partial slabs are compared instead of output + statistics; *ksplit_out = slabs); scaled: device output scale (dgrad route). */
+int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
+                            double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out, int* ksplit_out);
 #ifdef __cplusplus
 }
 #endif
