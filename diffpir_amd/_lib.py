@@ -39,11 +39,16 @@ class LoopDesc(C.Structure):
                 ("noise_init_dev", C.c_void_p), ("noise_n1_dev", C.c_void_p), ("noise_n2_dev", C.c_void_p),
                 ("seed", C.c_uint64), ("image_offset", C.c_int64), ("use_graph", C.c_int32),
                 ("skip_dead_final_eval", C.c_int32), ("generate_mode", C.c_int32), ("first_order", C.c_int32),
-                ("noise_rp_dev", C.c_void_p)]
+                ("noise_rp_dev", C.c_void_p), ("ddim_sample", C.c_int32)]
 
 
 class DpsCoef(C.Structure):
-    _fields_ = [("pc1", C.c_float), ("pc2", C.c_float), ("min_log", C.c_float), ("max_log", C.c_float)]
+    _fields_ = [("pc1", C.c_float), ("pc2", C.c_float), ("min_log", C.c_float), ("max_log", C.c_float), ("sa_prev", C.c_float), ("s1m_prev", C.c_float)]
+
+
+class PSampleCoef(C.Structure):
+    _fields_ = [("c1", C.c_float), ("c2", C.c_float), ("pc1", C.c_float), ("pc2", C.c_float), ("min_log", C.c_float), ("max_log", C.c_float),
+                ("ddim", C.c_int32), ("sa_prev", C.c_float), ("s1m_prev", C.c_float)]
 
 
 class DegradeDesc(C.Structure):
@@ -57,6 +62,7 @@ PROF_NAMES = ["conv3x3", "conv1x1", "groupnorm_stats", "attention", "fft_prox", 
 # name -> (restype, argtypes); every symbol declared in include/diffpir_engine.h
 SIGNATURES = {
     "dpir_version": (C.c_int, []),
+    "dpir_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "dpir_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
     "dpir_destroy": (None, [C.c_void_p]),
     "dpir_last_error": (C.c_char_p, [C.c_void_p]),
@@ -76,6 +82,9 @@ SIGNATURES = {
     "dpir_unet_vjp": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_run_dps_loop": (C.c_int, [C.c_void_p, C.POINTER(LoopDesc), C.POINTER(Step), C.POINTER(DpsCoef), C.c_int, C.c_int, C.c_float,
                                     C.c_void_p, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p]),
+    "dpir_p_sample": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(PSampleCoef), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "dpir_eps_from_xstart": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_float, C.c_int, C.c_void_p, C.c_size_t]),
+    "dpir_grad_and_value": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_unet_read_tap": (C.c_int, [C.c_void_p, C.c_char_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_size_t)]),
     "dpir_prox_fft_precalc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                         C.c_int, C.POINTER(C.c_void_p)]),
@@ -91,6 +100,7 @@ SIGNATURES = {
     "dpir_repaint_mix": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_finalize": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "dpir_ewise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t]),
     "dpir_comm_unique_id": (C.c_int, [C.c_void_p]),
     "dpir_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dpir_allgather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),

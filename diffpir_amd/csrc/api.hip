@@ -123,6 +123,14 @@ extern "C" {
 
 int dpir_version(void) { return DPIR_ABI_VERSION; }
 
+int dpir_device_count(int* n_out) {
+    if (!n_out) return DPIR_ERR_INVALID;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) { (void)hipGetLastError(); count = 0; }
+    *n_out = count;
+    return DPIR_OK;
+}
+
 int dpir_create(int device, dpir_engine** out) {
     if (!out) return DPIR_ERR_INVALID;
     *out = nullptr;
@@ -599,6 +607,14 @@ int dpir_randn(dpir_engine* e, float* out, uint64_t seed, uint64_t stream_id, in
     return DPIR_OK;
 }
 
+int dpir_ewise(dpir_engine* e, int op, const float* x_dev, const float* y_dev, size_t y_numel, float scalar, float* out_dev, size_t numel) {
+    if (!e || !x_dev || !out_dev) return fail(e, invalid("dpir_ewise: null argument"));
+    (void)hipSetDevice(e->device);
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_ewise(e->stream, op, x_dev, y_dev, y_numel, scalar, out_dev, numel));
+    return DPIR_OK;
+}
+
 // ------------------------------------------------------------------------------------------ degradation + metrics
 int dpir_degrade(dpir_engine* e, const dpir_degrade_desc* d, const uint8_t* gt, const float* k, const uint8_t* mask, const float* noise, float* y) {
     if (!e || !d || !gt || !y) return fail(e, invalid("dpir_degrade: null argument"));
@@ -906,7 +922,129 @@ int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* ste
     return DPIR_OK;
 }
 
-// ------------------------------------------------------------------------------------------ DPS_y0 loop (8f-4)
+// ------------------------------------------------------------------------------------------ gradient-mode plugs + DPS loop (8f-4)
+// The batch-wide residual norm from the per-workgroup partial sums.  With a communicator of more than one rank the squared sums are
+// all-reduced first: DPS_y0's update x = xt - d norm / d x has no `* norm` factor, so the GLOBAL batch norm of the reference
+// (torch.linalg.norm over the whole batch, utils_model.py:392) must be used or the result would depend on the sharding.
+static Status dps_norm(dpir_engine* e, const double* part, int nparts, float* normv) {
+    double* ssq = nullptr;
+    DPIR_TRY(e->ws.getT("dps#ssq", (size_t)2, &ssq));
+    DPIR_TRY(launch_norm_fold_ssq(e->stream, part, nparts, ssq));
+    if (e->comm && e->comm_world > 1) DPIR_TRY(comm_allreduce_sum_f64(e, ssq, 1));
+    return launch_norm_sqrt(e->stream, ssq, normv);
+}
+
+// model_fn(..., 'pred_x_prev_and_start') = one denoiser call + p_sample / ddim_sample(eta = 0) (utils_model.py:219-243).  In gradient mode the
+// forward leaves its tape and the clamp mask behind for dps_grad_through_network.
+static Status p_sample_impl(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, const PSampleCoef& cf, const float* noise, float* out6,
+                            float* xt, float* x0, int B, int H, int W) {
+    const int oc = e->net.desc.out_channels;
+    if (oc != 6) return Status{DPIR_ERR_UNSUPPORTED, "p_sample needs a learn_sigma model (out_channels == 6): the learned-range variance is read from channels 3..5"};
+    unsigned char* inside = nullptr;
+    DPIR_TRY(e->ws.getT("dps#inside", (size_t)B * 3 * H * W, &inside));
+    DPIR_TRY(unet_forward(e, x, t_dev, y_dev, out6, B, H, W));
+    ProfScope ps(&e->prof, PC_ELEM);
+    DPIR_TRY(launch_psample(e->stream, x, out6, oc, noise, cf, x0, xt, inside, B, H * W));
+    e->ps_c1 = cf.c1; e->ps_c2 = cf.c2; e->ps_B = B; e->ps_H = H; e->ps_W = W; e->ps_x0 = x0;
+    return Status{};
+}
+
+// d || m - Resizer(x_hat) || / d x_hat, un-normalised: diff = m - Resizer(x_hat) (kept), the norm (device float), gup = Resizer^T diff.
+// measurement = sa (ma y + mb) + s1m noise.
+static Status dps_residual(dpir_engine* e, const float* x_hat, const float* y, float ma, float mb, float sa, float s1m, const float* noise, int sf,
+                           int B, int H, int W, float** gup_out, float** norm_out) {
+    const int h = H / sf, w = W / sf;
+    const size_t total = (size_t)B * 3 * H * W, small = (size_t)B * 3 * h * w;
+    hipStream_t s = e->stream;
+    float *down = nullptr, *diff = nullptr, *gmid = nullptr, *gup = nullptr, *normv = nullptr; double* part = nullptr;
+    DPIR_TRY(e->ws.getT("dps#down", small, &down));
+    DPIR_TRY(e->ws.getT("dps#diff", small, &diff));
+    DPIR_TRY(e->ws.getT("dps#gmid", (size_t)B * 3 * h * W, &gmid));
+    DPIR_TRY(e->ws.getT("dps#gup", total, &gup));
+    DPIR_TRY(e->ws.getT("dps#part", (size_t)256, &part));
+    DPIR_TRY(e->ws.getT("dps#norm", (size_t)4, &normv));
+    ResizerTab th, tw;
+    DPIR_TRY(e->resizer(H, sf, &th));
+    DPIR_TRY(e->resizer(W, sf, &tw));
+    DPIR_TRY(resize_down_impl(e, x_hat, 1.f, 0.f, down, sf, B, H, W));
+    DPIR_TRY(launch_diff_norm(s, y, ma, mb, down, diff, small, part, 256, nullptr, sa, s1m, noise));
+    DPIR_TRY(dps_norm(e, part, 256, normv));
+    // Resizer^T: the forward resamples dim 2 (H) first, then dim 3 (W) -> adjoint W first, then H
+    DPIR_TRY(launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
+    DPIR_TRY(launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
+    *gup_out = gup; *norm_out = normv;
+    return Status{};
+}
+
+// torch.autograd.grad(norm, x) with x_hat = x0 of the last p_sample_impl(x): the clamp mask, the direct c1 term and the network backward.
+// Leaves direct / dx_net in the workspace (norm_grad = direct + dx_net).
+static Status dps_grad_through_network(dpir_engine* e, const float* gup, const float* normv, float** direct_out, float** dxn_out) {
+    const int B = e->ps_B, H = e->ps_H, W = e->ps_W, oc = e->net.desc.out_channels;
+    const size_t total = (size_t)B * 3 * H * W;
+    float *dout6 = nullptr, *direct = nullptr, *dxn = nullptr; unsigned char* inside = nullptr;
+    DPIR_TRY(e->ws.getT("dps#dout6", (size_t)B * oc * H * W, &dout6));
+    DPIR_TRY(e->ws.getT("dps#direct", total, &direct));
+    DPIR_TRY(e->ws.getT("dps#dxn", total, &dxn));
+    DPIR_TRY(e->ws.getT("dps#inside", total, &inside));
+    DPIR_TRY(launch_dps_seed(e->stream, gup, normv, inside, e->ps_c1, e->ps_c2, oc, dout6, direct, B, H * W));
+    DPIR_TRY(unet_backward(e, dout6, dxn));
+    *direct_out = direct; *dxn_out = dxn;
+    return Status{};
+}
+
+int dpir_p_sample(dpir_engine* e, const float* x_dev, int t, const dpir_psample_coef* c, const float* noise_dev, const int64_t* y_host,
+                  float* xt_out_dev, float* x0_out_dev, int B, int H, int W) {
+    if (!e || !x_dev || !c || !noise_dev || !xt_out_dev || !x0_out_dev || B <= 0 || H <= 0 || W <= 0) return fail(e, invalid("dpir_p_sample: bad argument"));
+    (void)hipSetDevice(e->device);
+    if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
+    if ((e->net.desc.num_classes > 0) != (y_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
+    range_clear(e);
+    std::vector<int64_t> tv(B, t);
+    int *t_dev = nullptr, *y_dev = nullptr;
+    float* out6 = nullptr;
+    API_TRY(e, upload_ints(e, "api#t", tv.data(), B, &t_dev));
+    API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
+    API_TRY(e, e->ws.getT("loop#out6", (size_t)B * e->net.desc.out_channels * H * W, &out6));
+    PSampleCoef cf{c->c1, c->c2, c->pc1, c->pc2, c->min_log, c->max_log, t != 0 ? 1.0f : 0.0f, c->ddim, c->sa_prev, c->s1m_prev};
+    API_TRY(e, p_sample_impl(e, x_dev, t_dev, y_dev, cf, noise_dev, out6, xt_out_dev, x0_out_dev, B, H, W));
+    return DPIR_OK;
+}
+
+int dpir_eps_from_xstart(dpir_engine* e, const float* x_dev, const float* x0_dev, float sqrt_ac, float sqrt_1m_ac, int score, float* out_dev, size_t numel) {
+    if (!e || !x_dev || !x0_dev || !out_dev) return fail(e, invalid("dpir_eps_from_xstart: null argument"));
+    (void)hipSetDevice(e->device);
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, launch_eps_from_xstart(e->stream, x_dev, x0_dev, sqrt_ac, sqrt_1m_ac, score, out_dev, numel));
+    return DPIR_OK;
+}
+
+int dpir_grad_and_value(dpir_engine* e, int through_network, const float* x_hat_dev, const float* measurement_dev, int sf, float* norm_grad_out_dev,
+                        float* norm_out_dev, int B, int H, int W) {
+    if (!e || !x_hat_dev || !measurement_dev || !norm_grad_out_dev || B <= 0 || sf < 1 || H % sf || W % sf)
+        return fail(e, invalid("dpir_grad_and_value: bad argument"));
+    (void)hipSetDevice(e->device);
+    float *gup = nullptr, *normv = nullptr;
+    const size_t total = (size_t)B * 3 * H * W;
+    if (through_network) {
+        if (!e->grad_enabled) return fail(e, Status{DPIR_ERR_STATE, "grad_and_value through the denoiser needs gradient mode: dpir_enable_grad before dpir_load_unet"});
+        if (!e->tape.valid || e->ps_x0 != x_hat_dev || e->ps_B != B || e->ps_H != H || e->ps_W != W)
+            return fail(e, Status{DPIR_ERR_STATE, "grad_and_value(x, x_hat): x_hat must be the pred_xstart output of the LAST dpir_p_sample call on this engine "
+                                                  "(the tape of that forward is what the gradient runs through)"});
+    }
+    ProfScope ps(&e->prof, PC_ELEM);
+    API_TRY(e, dps_residual(e, x_hat_dev, measurement_dev, 1.f, 0.f, 1.f, 0.f, nullptr, sf, B, H, W, &gup, &normv));
+    if (through_network) {
+        float *direct = nullptr, *dxn = nullptr;
+        API_TRY(e, dps_grad_through_network(e, gup, normv, &direct, &dxn));
+        API_TRY(e, launch_dps_update(e->stream, nullptr, direct, dxn, 0.f, nullptr, norm_grad_out_dev, total));
+    } else {
+        // norm_grad = -gup / norm: grad_step with src = 0, lam * nv / rho * tail = 1  ->  dst = 0 - ng  ... evaluated as a plain scale instead
+        API_TRY(e, launch_neg_scale_by_norm(e->stream, gup, normv, norm_grad_out_dev, total));
+    }
+    if (norm_out_dev) API_HIP(e, hipMemcpyAsync(norm_out_dev, normv, sizeof(float), hipMemcpyDeviceToDevice, e->stream));
+    return DPIR_OK;
+}
+
 int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* steps, const dpir_dps_coef* coefs, int n_steps,
                       int variant, float lambda_, const float* noise_ps_dev, const float* noise_yt_dev, float step_scale, float* out_f32,
                       uint8_t* out_u8) {
@@ -926,8 +1064,7 @@ int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step*
     hipStream_t s = e->stream;
     range_clear(e);
     LoopBufs b{};
-    float *xprev = nullptr, *down = nullptr, *diff = nullptr, *gmid = nullptr, *gup = nullptr, *dout6 = nullptr, *direct = nullptr, *dxn = nullptr, *normv = nullptr;
-    unsigned char* inside = nullptr; double* part = nullptr;
+    float *xprev = nullptr, *diff = nullptr;
     API_TRY(e, e->ws.getT("loop#x", total, &b.x));
     API_TRY(e, e->ws.getT("loop#x0", total, &b.x0));
     API_TRY(e, e->ws.getT("loop#out6", (size_t)B * oc * H * W, &b.out6));
@@ -935,20 +1072,8 @@ int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step*
     API_TRY(e, e->ws.getT("loop#init", total, &b.init_src));
     API_TRY(e, e->ws.getT("loop#t", (size_t)B, &b.t_dev));
     API_TRY(e, e->ws.getT("dps#xprev", total, &xprev));
-    API_TRY(e, e->ws.getT("dps#down", small, &down));
     API_TRY(e, e->ws.getT("dps#diff", small, &diff));
-    API_TRY(e, e->ws.getT("dps#gmid", (size_t)B * 3 * h * W, &gmid));
-    API_TRY(e, e->ws.getT("dps#gup", total, &gup));
-    API_TRY(e, e->ws.getT("dps#dout6", (size_t)B * oc * H * W, &dout6));
-    API_TRY(e, e->ws.getT("dps#direct", total, &direct));
-    API_TRY(e, e->ws.getT("dps#dxn", total, &dxn));
-    API_TRY(e, e->ws.getT("dps#inside", total, &inside));
-    API_TRY(e, e->ws.getT("dps#part", (size_t)256, &part));
-    API_TRY(e, e->ws.getT("dps#norm", (size_t)4, &normv));
     API_TRY(e, upload_ints(e, "loop#y", d.labels_host, B, &b.y_dev));
-    ResizerTab th, tw;
-    API_TRY(e, e->resizer(H, sf, &th));
-    API_TRY(e, e->resizer(W, sf, &tw));
     // init (main_ddpir.py:293-315): bicubic up-sampling of y, forward noising to t_start
     {
         ProfScope ps(&e->prof, PC_ELEM);
@@ -963,36 +1088,33 @@ int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step*
         std::vector<int64_t> tv(B, st.t);
         int* t_dev = nullptr;
         API_TRY(e, upload_ints(e, "loop#tt", tv.data(), B, &t_dev));
-        API_TRY(e, unet_forward(e, b.x, t_dev, b.y_dev, b.out6, B, H, W));
-        if (st.last) continue;                                   // the final denoiser call is dead (main_ddpir.py:384, 470)
+        if (st.last) {                                            // the final denoiser call is dead (main_ddpir.py:384, 470)
+            API_TRY(e, unet_forward(e, b.x, t_dev, b.y_dev, b.out6, B, H, W));
+            continue;
+        }
         const float* nz = noise_ps_dev ? noise_ps_dev + (size_t)i * total : nullptr;
+        if (!nz) { ProfScope ps(&e->prof, PC_ELEM); API_TRY(e, launch_randn(s, b.n2, d.seed, (uint64_t)4 * (i + 1), d.image_offset, B, (size_t)3 * H * W)); nz = b.n2; }
+        PSampleCoef cf{st.c1, st.c2, coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log, st.t != 0 ? 1.0f : 0.0f,
+                       d.ddim_sample, coefs[i].sa_prev, coefs[i].s1m_prev};
+        API_TRY(e, p_sample_impl(e, b.x, t_dev, b.y_dev, cf, nz, b.out6, xprev, b.x0, B, H, W));
         ProfScope ps(&e->prof, PC_ELEM);
-        if (!nz) { API_TRY(e, launch_randn(s, b.n2, d.seed, (uint64_t)4 * (i + 1), d.image_offset, B, (size_t)3 * H * W)); nz = b.n2; }
-        PSampleCoef cf{st.c1, st.c2, coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log, st.t != 0 ? 1.0f : 0.0f};
-        API_TRY(e, launch_psample(s, b.x, b.out6, oc, nz, cf, b.x0, xprev, inside, B, H * W));
+        float *gup = nullptr, *normv = nullptr;
         if (variant == 1) {
             // DPS_yt (main_ddpir.py:439-445): the measurement is noised to level t, the residual is taken at xt = p_sample's sample and
-            // differentiated w.r.t. xt itself -- no backward through the network
+            // differentiated w.r.t. xt itself -- no backward through the network (the norm cancels: no cross-rank exchange needed)
             const float* ny = noise_yt_dev ? noise_yt_dev + (size_t)i * small : nullptr;
             if (!ny) { API_TRY(e, launch_randn(s, diff, d.seed, (uint64_t)4 * (i + 1) + 1, d.image_offset, B, (size_t)3 * h * w)); ny = diff; }
             float* nyb = nullptr;
             API_TRY(e, e->ws.getT("dps#ny", small, &nyb));
             API_HIP(e, hipMemcpyAsync(nyb, ny, small * sizeof(float), hipMemcpyDeviceToDevice, s));
-            API_TRY(e, resize_down_impl(e, xprev, 1.f, 0.f, down, sf, B, H, W));
-            API_TRY(e, launch_diff_norm(s, d.y_dev, 2.f, -1.f, down, diff, small, part, 256, normv, st.sa_t, st.s1m_t, nyb));
-            API_TRY(e, launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
-            API_TRY(e, launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
+            API_TRY(e, dps_residual(e, xprev, d.y_dev, 2.f, -1.f, st.sa_t, st.s1m_t, nyb, sf, B, H, W, &gup, &normv));
             API_TRY(e, launch_grad_step(s, xprev, gup, normv, lambda_, st.tau, 0.35f, b.x, total));
             continue;
         }
         // difference = (2y - 1) - Resizer(x0), norm over the whole batch (utils_model.py:391-392)
-        API_TRY(e, resize_down_impl(e, b.x0, 1.f, 0.f, down, sf, B, H, W));
-        API_TRY(e, launch_diff_norm(s, d.y_dev, 2.f, -1.f, down, diff, small, part, 256, normv));
-        // Resizer^T: the forward resamples dim 2 (H) first, then dim 3 (W) -> adjoint W first, then H
-        API_TRY(e, launch_band_resample_T(s, diff, tw.w, tw.idx, tw.taps, B * 3 * h, W, w, 1, 1.f, gmid));
-        API_TRY(e, launch_band_resample_T(s, gmid, th.w, th.idx, th.taps, B * 3, H, h, W, 1.f, gup));
-        API_TRY(e, launch_dps_seed(s, gup, normv, inside, st.c1, st.c2, oc, dout6, direct, B, H * W));
-        API_TRY(e, unet_backward(e, dout6, dxn));
+        float *direct = nullptr, *dxn = nullptr;
+        API_TRY(e, dps_residual(e, b.x0, d.y_dev, 2.f, -1.f, 1.f, 0.f, nullptr, sf, B, H, W, &gup, &normv));
+        API_TRY(e, dps_grad_through_network(e, gup, normv, &direct, &dxn));
         API_TRY(e, launch_dps_update(s, xprev, direct, dxn, step_scale, b.x, nullptr, total));
     }
     {

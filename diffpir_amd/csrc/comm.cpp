@@ -52,6 +52,15 @@ int fail(dpir_engine* e, int code, const std::string& msg) {
 }
 }  // namespace
 
+namespace dpir {
+Status comm_allreduce_sum_f64(dpir_engine* e, double* dev, size_t n) {
+    if (!e->comm) return Status{DPIR_ERR_STATE, "comm_allreduce_sum_f64: no communicator"};
+    int rc = g_rccl.AllReduce(dev, dev, n, kNcclFloat64, /*ncclSum*/ 0, e->comm, e->stream);
+    if (rc != 0) return Status{DPIR_ERR_HIP, "ncclAllReduce(sum, f64): " + g_rccl.what(rc)};
+    return Status{};
+}
+}  // namespace dpir
+
 extern "C" {
 
 int dpir_comm_unique_id(void* id128_out) {

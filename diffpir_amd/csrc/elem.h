@@ -33,6 +33,8 @@ Status launch_repaint_mix(hipStream_t s, float* x, const float* y, const uint8_t
                           const StepDev* sp = nullptr, size_t noise_step_stride = 0, const LoopDev* lp = nullptr);
 Status launch_init_x(hipStream_t s, const float* src, const uint8_t* mask, const float* noise, float sa, float s1m, float* x, size_t total);
 Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW);
+// out[i] = x[i] op rhs, rhs = y[i] (y_numel == total) | y[0] (y_numel == 1) | scalar (y == null); op: 0 add, 1 sub, 2 mul, 3 div, 4 rhs - x, 5 rhs / x
+Status launch_ewise(hipStream_t s, int op, const float* x, const float* y, size_t y_numel, float scalar, float* out, size_t total);
 Status launch_affine(hipStream_t s, const float* x, float a, float b, float* out, size_t total);
 Status launch_band_resample(hipStream_t s, const float* in, const float* w, const int* idx, int taps, int P, int L_in,
                             int L_out, int inner, float pa, float pb, float* out);

@@ -130,6 +130,34 @@ __global__ void finalize_kernel(const float* x, float* of, uint8_t* ou, int HW, 
         }
     }
 }
+// One float32 operation per element, rounded once, as a torch elementwise op does (this file is built with -ffp-contract=off).
+__global__ void ewise_kernel(int op, const float* x, const float* y, int y_bcast, float scalar, float* out, size_t total) {
+    const float ys = y && y_bcast ? y[0] : scalar;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const float a = x[i], b = (y && !y_bcast) ? y[i] : ys;
+        float r;
+        switch (op) {
+            case 0: r = a + b; break;
+            case 1: r = a - b; break;
+            case 2: r = a * b; break;
+            case 3: r = a / b; break;
+            case 4: r = b - a; break;
+            default: r = b / a; break;
+        }
+        out[i] = r;
+    }
+}
+Status launch_ewise(hipStream_t s, int op, const float* x, const float* y, size_t y_numel, float scalar, float* out, size_t total) {
+    if (op < 0 || op > 5) return Status{DPIR_ERR_INVALID, "ewise: unknown op"};
+    if (y && y_numel != 1 && y_numel != total) return Status{DPIR_ERR_INVALID, "ewise: the second operand must have the same number of elements or one"};
+    if (!total) return Status{};
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 65536) blocks = 65536;
+    hipLaunchKernelGGL(ewise_kernel, dim3((unsigned)blocks), dim3(256), 0, s, op, x, y, (int)(y && y_numel == 1), scalar, out, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
 Status launch_finalize(hipStream_t s, const float* x, float* of, uint8_t* ou, int B, int HW) {
     size_t total = (size_t)B * 3 * HW;
     hipLaunchKernelGGL(finalize_kernel, grid1d(total), dim3(256), 0, s, x, of, ou, HW, total);

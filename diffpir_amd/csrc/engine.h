@@ -107,6 +107,8 @@ struct dpir_engine {
     int precision = 0;           // 0: exact fp32 MFMA kernels; 1: operand-split f16x3 MFMA (fp32-equivalent accuracy)
     bool grad_enabled = false;   // dpir_enable_grad before dpir_load_unet: dgrad weight packs + a tape per forward (DPS modes, 8f-4)
     dpir::Tape tape;
+    // the last p_sample (dpir_p_sample / the DPS loop): what dpir_grad_and_value(x, x_hat = that call's pred_xstart) differentiates through
+    float ps_c1 = 0.f, ps_c2 = 0.f; int ps_B = 0, ps_H = 0, ps_W = 0; const float* ps_x0 = nullptr;
     // Captured restoration steps.  A graph depends only on what is baked into its kernel arguments: the shape / task /
     // mode fields below and the workspace generation; per-batch pointers, seed and image offset live in a device block
     // (dpir::LoopDev), so every batch of a test set replays the same graph.  Entries are compared field by field on a
@@ -146,4 +148,6 @@ Status unet_film_table(dpir_engine* e, const int* t_dev, int n_steps, float* tab
 // vector-Jacobian product of the LAST forward (grad mode): gout [B, out_channels, H, W] -> dx [B, 3, H, W]
 Status unet_backward(dpir_engine* e, const float* gout, float* dx);
 double unet_flops(const UNet& net, int H, int W, int cls = -1);
+// comm.cpp: SUM all-reduce of n device doubles in place over the engine's communicator, on the engine stream (DPS_y0's batch-wide norm)
+Status comm_allreduce_sum_f64(dpir_engine* e, double* dev, size_t n);
 }  // namespace dpir

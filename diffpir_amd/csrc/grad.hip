@@ -394,8 +394,13 @@ __global__ void psample_kernel(const float* x, const float* out6, int out_ch, co
         if (xprev) {
             const float frac = (vv + 1.0f) / 2.0f;
             const float lv = frac * cf.max_log + (1.0f - frac) * cf.min_log;
-            const float mean = cf.pc1 * xs + cf.pc2 * x[i];
-            xprev[i] = mean + cf.nonzero * expf(0.5f * lv) * noise[i];
+            if (cf.ddim) {      // eta = 0: eps re-derived from the clamped x0 (gaussian_diffusion.py:345-349, 566), sigma * noise == 0
+                const float e2 = (cf.c1 * x[i] - xs) / cf.c2;
+                xprev[i] = xs * cf.sa_prev + cf.s1m_prev * e2;
+            } else {
+                const float mean = cf.pc1 * xs + cf.pc2 * x[i];
+                xprev[i] = mean + cf.nonzero * expf(0.5f * lv) * noise[i];
+            }
         }
     }
 }
@@ -435,10 +440,43 @@ __global__ void norm_fold_kernel(const double* part, int n, float* norm_out) {
         norm_out[0] = (float)sqrt(s);
     }
 }
+__global__ void norm_fold_ssq_kernel(const double* part, int n, double* ssq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        double s = 0.0;
+        for (int i = 0; i < n; ++i) s += part[i];
+        ssq[0] = s;
+    }
+}
+__global__ void norm_sqrt_kernel(const double* ssq, float* norm_out) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) norm_out[0] = (float)sqrt(ssq[0]);
+}
+Status launch_norm_fold_ssq(hipStream_t s, const double* part, int n, double* ssq) {
+    hipLaunchKernelGGL(norm_fold_ssq_kernel, dim3(1), dim3(64), 0, s, part, n, ssq);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+Status launch_norm_sqrt(hipStream_t s, const double* ssq, float* norm_out) {
+    hipLaunchKernelGGL(norm_sqrt_kernel, dim3(1), dim3(64), 0, s, ssq, norm_out);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+__global__ void eps_from_xstart_kernel(const float* x, const float* x0, float sa, float s1m, int score, float* out, size_t total) {
+#pragma clang fp contract(off)
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        float v = (x[i] - sa * x0[i]) / s1m;
+        if (score) v = -v / s1m;
+        out[i] = v;
+    }
+}
+Status launch_eps_from_xstart(hipStream_t s, const float* x, const float* x0, float sa, float s1m, int score, float* out, size_t total) {
+    hipLaunchKernelGGL(eps_from_xstart_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, x0, sa, s1m, score, out, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
 Status launch_diff_norm(hipStream_t s, const float* y, float ma, float mb, const float* down, float* diff, size_t total, double* part, int nparts,
                         float* norm_out, float sa, float s1m, const float* noise, const LoopDev* lp) {
     hipLaunchKernelGGL(diff_norm_kernel, dim3(nparts), dim3(256), 0, s, y, ma, mb, sa, s1m, noise, down, diff, total, part, lp);
-    hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(64), 0, s, part, nparts, norm_out);
+    if (norm_out) hipLaunchKernelGGL(norm_fold_kernel, dim3(1), dim3(64), 0, s, part, nparts, norm_out);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -508,6 +546,18 @@ __global__ void dps_update_kernel(const float* xprev, const float* direct, const
 Status launch_dps_update(hipStream_t s, const float* xprev, const float* direct, const float* dx_net, float step_scale, float* x, float* grad_out,
                          size_t total) {
     hipLaunchKernelGGL(dps_update_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, xprev, direct, dx_net, step_scale, x, grad_out, total);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
+__global__ void neg_scale_by_norm_kernel(const float* gup, const float* norm, float* out, size_t total) {
+#pragma clang fp contract(off)
+    const float nv = norm[0];
+    const float inv = nv > 0.f ? 1.0f / nv : 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) out[i] = -(gup[i] * inv);
+}
+Status launch_neg_scale_by_norm(hipStream_t s, const float* gup, const float* norm, float* out, size_t total) {
+    hipLaunchKernelGGL(neg_scale_by_norm_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, gup, norm, out, total);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

@@ -128,36 +128,73 @@ def shutdown():
     _state.update(mode="single", engine=None)
 
 
+_SENTINEL = b"\xff" * 128          # rank 0 could not create a unique id: every rank falls back together
+
+
 def init_rccl(engine, rank: int, world: int, port: int = None):
     """Rank 0 creates the 128-byte ncclUniqueId and ships it to the other ranks over a TCP socket on MASTER_ADDR (stdlib;
-    rendezvous plumbing only), then every rank joins the communicator on its engine's device (dpir_comm_init)."""
+    rendezvous plumbing only), then every rank joins the communicator on its engine's device (dpir_comm_init).
+
+    The fallback decision is COLLECTIVE: rank 0 always opens the listener and answers every rank with either the id or a failure
+    sentinel, so a missing librccl on rank 0 sends all ranks to torch.distributed together instead of leaving the others spinning
+    on a dead port.  Both sides are bounded by DIFFPIR_RENDEZVOUS_TIMEOUT seconds (default 300: ranks reach this point after loading
+    the same checkpoint, but the 2 GB topologies take minutes to pack).  A peer introduces itself (b"DPIR" + rank) before it is
+    answered; anything else is dropped."""
     import ctypes as C
     import socket
+    import struct
     import time
     buf = C.create_string_buffer(128)
     addr = os.environ.get("MASTER_ADDR", "127.0.0.1")
     port = port or int(os.environ.get("MASTER_PORT", "29533")) + 17
+    deadline = time.monotonic() + float(os.environ.get("DIFFPIR_RENDEZVOUS_TIMEOUT", "300"))
     if rank == 0:
-        engine._check(engine.lib.dpir_comm_unique_id(buf))
+        failure = None
+        try:
+            engine._check(engine.lib.dpir_comm_unique_id(buf))
+        except Exception as ex:
+            failure = ex
         if world > 1:
             srv = socket.socket()
             srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
             srv.bind((addr, port))
             srv.listen(world)
-            for _ in range(world - 1):
-                c, _a = srv.accept()
-                c.sendall(buf.raw)
-                c.close()
-            srv.close()
+            served = set()
+            try:
+                while len(served) < world - 1:
+                    srv.settimeout(max(0.1, deadline - time.monotonic()))
+                    try:
+                        c, _a = srv.accept()
+                    except socket.timeout:
+                        raise RuntimeError(f"RCCL rendezvous: only ranks {sorted(served)} of {world - 1} peers connected before the timeout")
+                    c.settimeout(10)
+                    try:
+                        hello = c.recv(8)
+                        if len(hello) == 8 and hello[:4] == b"DPIR":
+                            peer = struct.unpack("<i", hello[4:])[0]
+                            if 0 < peer < world and peer not in served:
+                                c.sendall(_SENTINEL if failure is not None else buf.raw)
+                                served.add(peer)
+                    except OSError:
+                        pass
+                    finally:
+                        c.close()
+            finally:
+                srv.close()
+        if failure is not None:
+            raise failure
     else:
-        for attempt in range(6000):            # rank 0 may still be packing weights (up to minutes for the 2 GB topologies)
+        c = None
+        while time.monotonic() < deadline:     # rank 0 may still be packing weights
             try:
                 c = socket.create_connection((addr, port), timeout=5)
                 break
             except OSError:
                 time.sleep(0.1)
-        else:
+        if c is None:
             raise RuntimeError("RCCL rendezvous: rank 0 is not listening")
+        c.settimeout(max(1.0, deadline - time.monotonic()))
+        c.sendall(b"DPIR" + struct.pack("<i", rank))
         data = b""
         while len(data) < 128:
             chunk = c.recv(128 - len(data))
@@ -165,6 +202,8 @@ def init_rccl(engine, rank: int, world: int, port: int = None):
                 raise RuntimeError("RCCL rendezvous: short read of the unique id")
             data += chunk
         c.close()
+        if data == _SENTINEL:
+            raise RuntimeError("RCCL rendezvous: rank 0 could not create a unique id (librccl missing?)")
         buf.raw = data
     engine._check(engine.lib.dpir_comm_init(engine.h, world, rank, buf))
     engine.rccl = True
@@ -246,6 +285,21 @@ def all_gather_results(local, n_images: int, rank: int, world: int, engine=None)
     return back(out.to(local.device))
 
 
+def check_dps_sharding(engine, cfg, n_images: int, world: int):
+    """generate_mode DPS_y0 is the ONE mode that couples the images of a batch: grad_and_value takes the norm over the whole batch
+    (utils/utils_model.py:392) and the update `x = xt - norm_grad` (main_ddpir.py:437) has no `* norm` factor that would cancel it.
+    Sharded, every rank's loop therefore all-reduces the squared residual sums over the communicator (csrc/api.hip `dps_norm`) -- which
+    needs the C ABI's RCCL communicator on the engine and every rank inside the loop (no empty shard)."""
+    if world <= 1 or getattr(cfg, "generate_mode", "") != "DPS_y0":
+        return
+    if not getattr(engine, "rccl", False):
+        raise NotImplementedError("generate_mode DPS_y0 on several GPUs needs the default 'rccl' collective: the batch-wide residual norm is all-reduced "
+                                  "inside the loop through the engine's communicator (torch.distributed fallbacks cannot reach into the loop)")
+    if n_images < world:
+        raise NotImplementedError(f"generate_mode DPS_y0: a batch of {n_images} images cannot be sharded over {world} ranks (every rank must run the loop: "
+                                  "its all-reduce of the batch norm is collective)")
+
+
 def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int, world: int, image_offset: int = 0, seed: int = 0,
                     use_graph: bool = True, noise_source: str = "device", host_noise=None, cache: dict = None,
                     skip_dead_final_eval: bool = False):
@@ -259,6 +313,7 @@ def restore_sharded(engine, cfg, y, k=None, mask=None, labels=None, *, rank: int
     Returns (uint8 [n_images, H, W, 3] on every rank as an engine-owned DeviceArray, local fp32 DeviceArray)."""
     from . import restore
     n = y.shape[0]
+    check_dps_sharding(engine, cfg, n, world)
     lo, hi = shard_range(n, rank, world)
     sl = slice(lo, hi)
     H, W = y.shape[2] * cfg.sf, y.shape[3] * cfg.sf

@@ -73,6 +73,39 @@ class DeviceArray:
         self.engine._check(self.engine.lib.dpir_d2h(self.engine.h, out.ctypes.data, self.ptr, self.nbytes))
         return out
 
+    # ---- the loop body's own arithmetic (main_ddpir.py:437, 440, 444), one rounded float32 operation per element like a torch
+    # elementwise op (dpir_ewise); operands: DeviceArray of the same shape, a one-element DeviceArray (a 0-dim tensor such as
+    # `norm`), or a Python / numpy scalar (cast to float32 as torch does for a float32 tensor)
+    __array_ufunc__ = None          # numpy scalars (schedule-table entries) defer to __rmul__ / __radd__ ... below
+
+    def _ew(self, op: int, other) -> "DeviceArray":
+        if self.dtype != np.float32:
+            raise EngineError("arithmetic is defined for float32 device arrays")
+        out = DeviceArray(self.engine, self.shape, np.float32)
+        e = self.engine
+        if isinstance(other, DeviceArray):
+            if other.size not in (1, self.size):
+                raise EngineError(f"shape mismatch: {self.shape} vs {other.shape}")
+            e._check(e.lib.dpir_ewise(e.h, op, self.ptr, other.ptr, other.size, 0.0, out.ptr, self.size))
+        else:
+            e._check(e.lib.dpir_ewise(e.h, op, self.ptr, None, 0, float(np.float32(other)), out.ptr, self.size))
+        return out
+
+    def __add__(self, o): return self._ew(0, o)
+    def __radd__(self, o): return self._ew(0, o)
+    def __sub__(self, o): return self._ew(1, o)
+    def __rsub__(self, o): return self._ew(4, o)
+    def __mul__(self, o): return self._ew(2, o)
+    def __rmul__(self, o): return self._ew(2, o)
+    def __truediv__(self, o): return self._ew(3, o)
+    def __rtruediv__(self, o): return self._ew(5, o)
+    def __neg__(self): return self._ew(2, -1.0)
+
+    # torch idioms of the reference loop body that have no meaning for an engine array (gradients are the engine's tape)
+    def requires_grad_(self, flag=True): return self
+    def detach_(self): return self
+    def detach(self): return self
+
     def clone(self) -> "DeviceArray":
         o = DeviceArray(self.engine, self.shape, self.dtype)
         self.engine._check(self.engine.lib.dpir_d2d(self.engine.h, o.ptr, self.ptr, self.nbytes))
@@ -151,6 +184,23 @@ class Engine:
                                            _ptr(out), _ptr(dx), B, H, W))
         return out, dx
 
+    def p_sample(self, x, t: int, coef: "_lib.PSampleCoef", noise, y=None, xt=None, x0=None):
+        """(sample, pred_xstart) of GaussianDiffusion.p_sample / ddim_sample(eta=0) around one denoiser call (dpir_p_sample)."""
+        B, _, H, W = x.shape
+        yv = None if y is None else np.ascontiguousarray(y, dtype=np.int64)
+        xt = self.empty((B, 3, H, W)) if xt is None else xt
+        x0 = self.empty((B, 3, H, W)) if x0 is None else x0
+        self._check(self.lib.dpir_p_sample(self.h, _ptr(x), int(t), C.byref(coef), _ptr(noise), None if yv is None else yv.ctypes.data,
+                                           _ptr(xt), _ptr(x0), B, H, W))
+        return xt, x0
+
+    def grad_and_value(self, through_network: bool, x_hat, measurement, sf: int):
+        """(norm_grad [B,3,H,W], norm [1]) of || measurement - Resizer_{1/sf}(x_hat) ||_2 (dpir_grad_and_value)."""
+        B, _, H, W = x_hat.shape
+        g, nv = self.empty((B, 3, H, W)), self.empty((1,))
+        self._check(self.lib.dpir_grad_and_value(self.h, 1 if through_network else 0, _ptr(x_hat), _ptr(measurement), int(sf), g.ptr, nv.ptr, B, H, W))
+        return g, nv
+
     def load_unet(self, desc: "_lib.UNetDesc", state_dict: Dict[str, np.ndarray]):
         n = len(state_dict)
         arr = (_lib.Tensor * n)()
@@ -214,6 +264,13 @@ class Engine:
         cnt = (C.c_int64 * _lib.PROF_CLASSES)()
         self._check(self.lib.dpir_prof_read(self.h, ms, cnt))
         return {_lib.PROF_NAMES[i]: (ms[i], cnt[i]) for i in range(_lib.PROF_CLASSES)}
+
+
+def device_count() -> int:
+    """HIP devices visible to this process (dpir_device_count; the reference: torch.cuda.device_count(), main_ddpir.py:135)."""
+    n = C.c_int(0)
+    _lib.load().dpir_device_count(C.byref(n))
+    return int(n.value)
 
 
 _default: Dict[int, Engine] = {}

@@ -185,7 +185,19 @@ def main(argv=None):
             per_img = np.zeros((0, 2))
             u8_local = eng.empty((hi - lo, H, W, 3), np.uint8)          # engine-owned result buffer (send side of the all-gather)
             drawn = None
-            if noise == "host":
+            dps_mode = cfg.generate_mode in ("DPS_y0", "DPS_yt")
+            ddist.check_dps_sharding(eng, cfg, n_b, world)
+            dps_nf = None
+            if noise == "host" and dps_mode:
+                # the DPS modes draw in their own order (init, then per step the sampler's draw [and the y_t draw]); restore_batch pulls
+                # them through noise_fn.  The GLOBAL batch's tensor is drawn every time and this rank keeps its image rows, so results do
+                # not depend on the number of ranks; a rank with an empty shard still advances the shared generator.
+                dps_nf = lambda shape: torch.randn((n_b,) + tuple(shape[1:]), generator=host_gen).numpy()[lo:hi]
+                if hi == lo:
+                    _, steps, _ = restore._steps(cfg)
+                    for shp in restore.dps_host_noise_shapes(cfg, steps, 0, H, W):
+                        dps_nf(shp)
+            elif noise == "host":
                 # EVERY rank draws the global batch's noise, also a rank whose shard is empty (ragged last batch with fewer images
                 # than ranks): the shared generator must advance identically everywhere or later batches depend on the world size
                 _, steps, _ = restore._steps(cfg)
@@ -199,8 +211,8 @@ def main(argv=None):
                 y, ops = dgr.degrade(eng, config.task, gt[sl], k=None if k_all is None else k_all[sl], mask=None if mask_all is None else mask_all[sl],
                                      noise_level_img=config.noise_level_img, sf=config.sf, sr_mode=config.sr_mode, seed=config.seed + 1,
                                      image_offset=i0 + lo)
-                out_f32 = restore.restore_batch(eng, cfg, y, k=ops.get("k"), mask=ops.get("mask"), noise_source=noise, predrawn=drawn,
-                                                seed=config.seed, image_offset=i0 + lo, use_graph=use_graph, out_u8=u8_local, _cache=cache,
+                out_f32 = restore.restore_batch(eng, cfg, y, k=ops.get("k"), mask=None if dps_mode else ops.get("mask"), noise_source=noise,
+                                                predrawn=drawn, noise_fn=dps_nf, seed=config.seed, image_offset=i0 + lo, use_graph=use_graph, out_u8=u8_local, _cache=cache,
                                                 skip_dead_final_eval=bool(config.get("engine_skip_dead_final_eval", False)))
                 psnr_i, psnr_y_i = dgr.metrics(eng, out_f32, ops["gt"])            # dpir_metrics: per-image PSNR / PSNR-Y
                 per_img = np.stack([psnr_i, psnr_y_i], 1).astype(np.float64)

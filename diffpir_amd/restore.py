@@ -216,6 +216,18 @@ def restore_batch(engine: Engine, cfg: LoopConfig, y, k=None, mask=None, labels=
     return (out_f32, out_u8) if return_u8 else out_f32
 
 
+def dps_host_noise_shapes(cfg: LoopConfig, steps, B: int, H: int, W: int):
+    """Shapes of the reference's randn_like draws in the DPS modes, in call order: init, then per step the sampler's draw
+    (gaussian_diffusion.py:430 / :577, every step incl. the dead final one) and, DPS_yt on non-final steps, the y_t draw (main_ddpir.py:440)."""
+    h, w = H // cfg.sf, W // cfg.sf
+    shapes = [(B, 3, H, W)]
+    for st in steps:
+        shapes.append((B, 3, H, W))
+        if cfg.generate_mode == "DPS_yt" and not st["last"]:
+            shapes.append((B, 3, h, w))
+    return shapes
+
+
 def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_offset, skip_dead_final_eval, out_f32, out_u8, return_u8):
     """generate_mode 'DPS_y0' / 'DPS_yt' (main_ddpir.py:370-373, 433-445): dpir_run_dps_loop.  Host noise order: init, then per step the
     p_sample draw and (DPS_yt, non-final steps) the y_t draw; there is no re-noising in these modes (main_ddpir.py:448)."""
@@ -228,6 +240,7 @@ def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_off
     coefs = (_lib.DpsCoef * len(steps))()
     for i, st in enumerate(steps):
         coefs[i].pc1, coefs[i].pc2, coefs[i].min_log, coefs[i].max_log = [float(v) for v in dtab.dps_coef(st["t"])]
+        coefs[i].sa_prev, coefs[i].s1m_prev = [float(v) for v in dtab.ddim_coef(st["t"])]
     yd = engine.to_device(y, np.float32) if isinstance(y, np.ndarray) else y
     B, _, h, w = yd.shape
     H, W = h * cfg.sf, w * cfg.sf
@@ -262,6 +275,8 @@ def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_off
     d.seed, d.image_offset = seed, image_offset
     d.skip_dead_final_eval = int(skip_dead_final_eval)
     d.generate_mode = GENERATE_MODES[cfg.generate_mode]
+    # config.ddim_sample reaches model_fn(..., 'pred_x_prev_and_start') (main_ddpir.py:371-373): xt is then ddim_sample(eta=0)'s sample
+    d.ddim_sample = 1 if cfg.ddim_sample else 0
     if out_f32 is None:
         out_f32 = engine.empty((B, 3, H, W))
     if out_u8 is None and return_u8:
@@ -273,8 +288,11 @@ def _restore_dps(engine, cfg, y, labels, noise_source, noise_fn, seed, image_off
 
 
 def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = None, labels=None):
-    """The reference's loop body (main_ddpir.py:291-470) against the drop-in plugs, host-fed noise."""
+    """The reference's loop body (main_ddpir.py:291-470) against the drop-in plugs, host-fed noise.  Every branch the monolithic
+    loops implement: the DiffPIR analytic step, the first-order data step (sub_1_analytic: false), DPS_y0 and DPS_yt -- the latter
+    three written with the reference's own expressions on device arrays (`xt - norm_grad * 1.`, ...)."""
     from . import utils_model, utils_sisr as sr
+    from .utils_resizer import Resizer
     eng: Engine = model.engine
     cfg.check_supported()
     dt, steps, arr = _steps(cfg)
@@ -283,8 +301,10 @@ def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=No
     shape = (B, 3, H, W)
     lib, hnd = eng.lib, eng.h
     x = eng.empty(shape)
+    dps = "DPS" in cfg.generate_mode
     # (3) initialize x (main_ddpir.py:293-315)
     if cfg.task == "sr":
+        degrade_op = Resizer(shape, 1 / cfg.sf, engine=eng)
         src = eng.empty(shape)
         eng._check(lib.dpir_bicubic_up(hnd, _ptr(y), src.ptr, cfg.sf, B, h, w))
         xs = src.numpy()
@@ -295,21 +315,51 @@ def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=No
     t_start = t_start_of(cfg, dt.reduced)
     n0 = np.asarray(noise_fn(shape), np.float32)
     x.copy_from(dt.sqrt_ac[t_start] * (np.float32(2) * xs - np.float32(1)) + dt.sqrt_1m_ac[t_start] * n0)
-    if cfg.task in ("sr", "deblur") and not (cfg.task == "sr" and cfg.sr_mode == "cubic"):
+    if cfg.task in ("sr", "deblur") and not (cfg.task == "sr" and cfg.sr_mode == "cubic") and not dps and cfg.sub_1_analytic:
         FB, FBC, F2B, FBFy = sr.pre_calculate(y, k, cfg.sf, engine=eng)
     kwargs = {} if labels is None else {"y": labels}
-    for i, st in enumerate(steps):
-        curr_sigma = dt.reduced[st["t"]]
-        if cfg.generate_mode == "repaint":                  # main_ddpir.py:355-358
-            nr = eng.to_device(np.asarray(noise_fn(shape), np.float32))
-            eng._check(lib.dpir_repaint_mix(hnd, x.ptr, _ptr(y), _ptr(mask), C.byref(arr[i]), nr.ptr, B, H, W))
-        x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type="pred_xstart", model_diffusion=model,
-                                  diffusion=diffusion, ddim_sample=False, alphas_cumprod=dt.alphas_cumprod, **kwargs)
-        noise_fn(shape)                                     # p_sample's draw
-        if not st["last"]:
-            tau = np.float32(st["tau"])
+    # the sampler's randn_like (gaussian_diffusion.py:430 / :577) and the loop's own draws come from ONE host stream, in call order
+    draw = lambda like: eng.to_device(np.asarray(noise_fn(like.shape), np.float32))
+    utils_model.set_randn_like(draw)
+    try:
+        for i, st in enumerate(steps):
+            curr_sigma = dt.reduced[st["t"]]
+            t_i = st["t"]
+            if cfg.generate_mode == "repaint":                  # main_ddpir.py:355-358
+                nr = eng.to_device(np.asarray(noise_fn(shape), np.float32))
+                eng._check(lib.dpir_repaint_mix(hnd, x.ptr, _ptr(y), _ptr(mask), C.byref(arr[i]), nr.ptr, B, H, W))
+            if dps:                                             # main_ddpir.py:370-373
+                x = x.requires_grad_()
+                xt, x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type="pred_x_prev_and_start", model_diffusion=model,
+                                              diffusion=diffusion, ddim_sample=cfg.ddim_sample, alphas_cumprod=dt.alphas_cumprod, **kwargs)
+            else:
+                x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type="pred_xstart", model_diffusion=model,
+                                          diffusion=diffusion, ddim_sample=cfg.ddim_sample, alphas_cumprod=dt.alphas_cumprod, **kwargs)
+                noise_fn(shape)                                 # p_sample's draw (unused for pred_xstart)
+            if st["last"]:
+                continue
+            tau = np.float32(st["tau"])                         # rhos[t_i]
+            if cfg.generate_mode == "DPS_y0":                   # main_ddpir.py:434-438
+                measurement = 2 * y - 1
+                norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=x, x_hat=x0, measurement=measurement)
+                x = xt - norm_grad * 1.
+                x = x.detach_()
+                continue
+            if cfg.generate_mode == "DPS_yt":                   # main_ddpir.py:439-445
+                y_t = dt.sqrt_ac[t_i] * (2 * y - 1) + dt.sqrt_1m_ac[t_i] * draw(y)
+                measurement = y_t
+                norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=xt, x_hat=xt, measurement=measurement)
+                x = xt - norm_grad * cfg.lambda_ * norm / tau * 0.35
+                x = x.detach_()
+                continue
             if cfg.generate_mode != "DiffPIR":
-                pass                                        # no data-fidelity step outside DiffPIR mode (main_ddpir.py:385)
+                pass                                            # no data-fidelity step outside DiffPIR mode (main_ddpir.py:385)
+            elif not cfg.sub_1_analytic:                        # main_ddpir.py:420-430 (task sr)
+                x0 = x0.requires_grad_()
+                measurement = 2 * y - 1
+                norm_grad, norm = utils_model.grad_and_value(operator=degrade_op, x=x0, x_hat=x0, measurement=measurement)
+                x0 = x0 - norm_grad * norm / tau
+                x0 = x0.detach_()
             elif cfg.task == "inpaint":
                 eng._check(lib.dpir_prox_mask(hnd, x0.ptr, _ptr(y), _ptr(mask), float(tau), cfg.guidance_scale, B, H, W))
             elif cfg.task == "deblur" or cfg.sr_mode == "blur":
@@ -323,6 +373,8 @@ def restore_batch_stepwise(model, diffusion, cfg: LoopConfig, y, k=None, mask=No
             n1 = eng.to_device(np.asarray(noise_fn(shape), np.float32))
             n2 = eng.to_device(np.asarray(noise_fn(shape), np.float32))
             eng._check(lib.dpir_renoise(hnd, x.ptr, x0.ptr, C.byref(arr[i]), n1.ptr, n2.ptr, B, H, W))
+    finally:
+        utils_model.set_randn_like(None)
     out = eng.empty(shape)
     eng._check(lib.dpir_finalize(hnd, x.ptr, out.ptr, None, B, H, W))
     eng.sync()

@@ -53,6 +53,7 @@ class DiffusionTables:
     posterior_mean_coef2: np.ndarray = None
     posterior_log_variance_clipped: np.ndarray = None
     log_betas: np.ndarray = None
+    alphas_cumprod_prev: np.ndarray = None
 
     @staticmethod
     def make(T=1000) -> "DiffusionTables":
@@ -63,7 +64,13 @@ class DiffusionTables:
         post_var = betas * (1.0 - ac_prev) / (1.0 - ac)
         return DiffusionTables(np.sqrt(1.0 / ac), np.sqrt(1.0 / ac - 1),
                                betas * np.sqrt(ac_prev) / (1.0 - ac), (1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac),
-                               np.log(np.append(post_var[1], post_var[1:])), np.log(betas))
+                               np.log(np.append(post_var[1], post_var[1:])), np.log(betas), ac_prev)
+
+    def ddim_coef(self, t: int):
+        """ddim_sample(eta = 0) (gaussian_diffusion.py:568-580): (sqrt(alpha_bar_prev), sqrt(1 - alpha_bar_prev - sigma^2)) with sigma = 0,
+        evaluated in float32 as the reference does on its _extract_into_tensor(...).float() tensors."""
+        abp = np.float32(self.alphas_cumprod_prev[t])
+        return np.sqrt(abp, dtype=np.float32), np.sqrt(np.float32(np.float32(1.0) - abp) - np.float32(0.0), dtype=np.float32)
 
     def dps_coef(self, t: int):
         """(posterior_mean_coef1, posterior_mean_coef2, min_log, max_log) at t as float32 (_extract_into_tensor(...).float())."""

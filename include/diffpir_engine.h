@@ -49,6 +49,9 @@ typedef struct dpir_prox dpir_prox;       /* opaque: FB / F2B / FBFy spectra of 
 
 /* ---- lifecycle -------------------------------------------------------------------------- */
 int dpir_version(void);
+/* number of HIP devices visible to this process (0 when there is none; never fails).  The reference reads
+ * torch.cuda.device_count() for its unused world_size (main_ddpir.py:135); the multi-GPU launcher and tests use this. */
+int dpir_device_count(int* n_out);
 /* device = HIP ordinal.  Fails with DPIR_ERR_HIP when no gfx950 device is visible. */
 int dpir_create(int device, dpir_engine** out);
 void dpir_destroy(dpir_engine* e);
@@ -176,6 +179,13 @@ int dpir_finalize(dpir_engine* e, const float* x_dev, float* out_f32_dev, uint8_
 int dpir_randn(dpir_engine* e, float* out_dev, uint64_t seed, uint64_t stream_id, int64_t image_offset,
                int B, int C, int H, int W);
 
+/* The loop body's own tensor arithmetic, for a loop that stays in the host language: main_ddpir.py:437 `x = xt - norm_grad * 1.`,
+ * :440 `sa_t * (2*y-1) + s1m_t * randn_like(y)`, :444 `xt - norm_grad * lambda_ * norm / rhos[t_i] * 0.35`.  One float32 operation per
+ * element, rounded once, like a torch elementwise op: out[i] = x[i] op rhs with rhs = y_dev[i] (y_numel == numel), y_dev[0]
+ * (y_numel == 1: a 0-dim tensor such as `norm`) or `scalar` (y_dev NULL).  op: 0 add, 1 sub, 2 mul, 3 div, 4 rhs - x, 5 rhs / x.
+ * out_dev may alias x_dev. */
+int dpir_ewise(dpir_engine* e, int op, const float* x_dev, const float* y_dev, size_t y_numel, float scalar, float* out_dev, size_t numel);
+
 /* ---- whole restoration loop (main_ddpir.py:291-470 for one batch) ------------------------- */
 typedef enum dpir_task { DPIR_TASK_DEBLUR = 0, DPIR_TASK_SR_BLUR = 1, DPIR_TASK_INPAINT = 2, DPIR_TASK_SR_CUBIC = 3 } dpir_task;
 
@@ -209,6 +219,8 @@ typedef struct dpir_loop_desc {
      * x0 <- x0 - d||(2y-1) - Resizer(x0)|| / dx0 * ||.|| / rho (super-resolution tasks, DiffPIR mode; no network backward) */
     int32_t first_order;
     const float* noise_rp_dev;    /* repaint, host-fed noise: [n_steps,B,3,H,W] in step order; NULL -> device Philox (draw 3) */
+    int32_t ddim_sample;          /* dpir_run_dps_loop: 1 -> x_prev from ddim_sample(eta=0) instead of p_sample (config.ddim_sample,
+                                   * utils_model.py:219-240).  dpir_run_loop ignores it: 'pred_xstart' is the same tensor either way. */
 } dpir_loop_desc;
 
 /* Runs init -> n_steps x ([repaint mix ->] UNet -> [prox ->] re-noise) -> finalize.  Outputs (either may be NULL):
@@ -228,7 +240,11 @@ int dpir_unet_vjp(dpir_engine* e, const float* x_dev, const int64_t* t_host, con
                   float* out_dev, float* dx_dev, int B, int H, int W);
 /* Per-step p_sample coefficients (gaussian_diffusion.py:153-167, 268-276: float64 tables cast to float32 by
  * _extract_into_tensor): posterior_mean_coef1/2[t], posterior_log_variance_clipped[t], log(betas[t]). */
-typedef struct dpir_dps_coef { float pc1, pc2, min_log, max_log; } dpir_dps_coef;
+typedef struct dpir_dps_coef {
+    float pc1, pc2, min_log, max_log;
+    float sa_prev, s1m_prev;      /* ddim_sample(eta=0) only: sqrt(alphas_cumprod_prev[t]), sqrt(1 - alphas_cumprod_prev[t]) in float32
+                                   * (gaussian_diffusion.py:568-580) */
+} dpir_dps_coef;
 /* generate_mode 'DPS_y0' for the super-resolution tasks (the only DPS variant the reference can run as shipped: its deblurring
  * operator raises at main_ddpir.py:302 and the inpainting branch never defines xt).  Per step:
  *   xt, x0 = p_sample(x)                       (model_fn 'pred_x_prev_and_start', utils_model.py:207-258)
@@ -242,6 +258,36 @@ typedef struct dpir_dps_coef { float pc1, pc2, min_log, max_log; } dpir_dps_coef
 int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, const dpir_dps_coef* coefs_host, int n_steps,
                       int variant, float lambda_, const float* noise_ps_dev, const float* noise_yt_dev, float step_scale,
                       float* out_f32_dev, uint8_t* out_u8_dev);
+
+/* The two plugs the reference's DPS / first-order branches call, for a loop body that stays in the host language (round 4):
+ *
+ * dpir_p_sample = utils_model.model_fn(x, ..., model_out_type='pred_x_prev_and_start' | 'pred_x_prev') (utils/utils_model.py:207-246,
+ *   called at main_ddpir.py:370-373): one denoiser call, then GaussianDiffusion.p_sample with the learned-range variance
+ *   (gaussian_diffusion.py:232-326, 395-439) or, with c->ddim, ddim_sample(eta = 0) (:537-585).  noise_dev [B,3,H,W] is the
+ *   randn_like draw of the sampler (required; ddim consumes it with sigma = 0).  Outputs xt ("sample") and x0 ("pred_xstart").
+ *   In gradient mode the call leaves the forward's tape and the clamp mask on the engine for dpir_grad_and_value.
+ *   Needs a learn_sigma model (out_channels == 6), else DPIR_ERR_UNSUPPORTED. */
+typedef struct dpir_psample_coef {
+    float c1, c2;                 /* sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t] */
+    float pc1, pc2, min_log, max_log;   /* as dpir_dps_coef */
+    int32_t ddim;
+    float sa_prev, s1m_prev;      /* as dpir_dps_coef */
+} dpir_psample_coef;
+int dpir_p_sample(dpir_engine* e, const float* x_dev, int t, const dpir_psample_coef* c, const float* noise_dev, const int64_t* y_host,
+                  float* xt_out_dev, float* x0_out_dev, int B, int H, int W);
+/* model_out_type 'epsilon' / 'score' (utils/utils_model.py:247-255): out = (x - sqrt_ac x0) / sqrt_1m_ac  [score: * -1 / sqrt_1m_ac]. */
+int dpir_eps_from_xstart(dpir_engine* e, const float* x_dev, const float* x0_dev, float sqrt_ac, float sqrt_1m_ac, int score,
+                         float* out_dev, size_t numel);
+/* dpir_grad_and_value = utils_model.grad_and_value(operator=Resizer(1/sf), x, x_hat, measurement) (utils/utils_model.py:390-394):
+ *   difference = measurement - Resizer(x_hat);  norm = ||difference||_2 over the WHOLE batch (all ranks of the communicator when one
+ *   with more than one rank is attached);  norm_grad = d norm / d x.
+ * through_network = 1: x is the input of the LAST dpir_p_sample on this engine and x_hat_dev its pred_xstart output (checked) -- the
+ *   gradient runs through the clamp and the denoiser (main_ddpir.py:436, generate_mode DPS_y0); gradient mode required.
+ * through_network = 0: x is x_hat itself (main_ddpir.py:425 first-order data step, :443 DPS_yt): norm_grad = -Resizer^T(difference) / norm.
+ * measurement_dev [B,3,H/sf,W/sf] in the operator's range (the reference passes 2y-1 or y_t).  norm_grad_out_dev [B,3,H,W];
+ * norm_out_dev: one device float (may be NULL).  Asynchronous. */
+int dpir_grad_and_value(dpir_engine* e, int through_network, const float* x_hat_dev, const float* measurement_dev, int sf,
+                        float* norm_grad_out_dev, float* norm_out_dev, int B, int H, int W);
 
 /* ---- multi-GPU: the one collective of the path ------------------------------ */
 /* One process and one engine per GPU; images are block-partitioned over ranks, no exchange inside the loop (the reference is

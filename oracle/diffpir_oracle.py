@@ -60,6 +60,7 @@ class DiffusionTables:
         self.posterior_mean_coef1 = betas * np.sqrt(ac_prev) / (1.0 - ac)
         self.posterior_mean_coef2 = (1.0 - ac_prev) * np.sqrt(1.0 - betas) / (1.0 - ac)
         self.log_betas = np.log(betas)
+        self.alphas_cumprod_prev = ac_prev
 
 
 def find_nearest(array, value) -> int:
@@ -103,6 +104,7 @@ class LoopConfig:
     generate_mode: str = "DiffPIR"       # DiffPIR | repaint | vanilla (the latter two: inpainting only) | DPS_y0 | DPS_yt (task sr)
     sub_1_analytic: bool = True          # False: first-order data step (main_ddpir.py:420-430; runnable for task sr)
     noise_init_img: object = "max"       # 'max' or a noise level in /255 units (main_ddpir.py:197-200)
+    ddim_sample: bool = False            # DPS modes: xt from ddim_sample(eta=0) instead of p_sample (utils_model.py:219-240)
 
     @property
     def sigma(self):                     # main_ddpir.py:141
@@ -306,7 +308,7 @@ def tensor2uint_batch(x01):
     return np.uint8((img * 255.0).round())
 
 
-def p_sample_prev_and_start(sd, hp, x, t_step: int, dtab: DiffusionTables, noise, y_label=None):
+def p_sample_prev_and_start(sd, hp, x, t_step: int, dtab: DiffusionTables, noise, y_label=None, ddim=False):
     """utils_model.model_fn(..., model_out_type='pred_x_prev_and_start') = GaussianDiffusion.p_sample with the LEARNED_RANGE
     variance (gaussian_diffusion.py:232-326, 395-439): returns (sample, pred_xstart), differentiable w.r.t. x."""
     vec_t = torch.tensor([t_step] * x.shape[0])
@@ -317,6 +319,12 @@ def p_sample_prev_and_start(sd, hp, x, t_step: int, dtab: DiffusionTables, noise
     frac = (v + 1) / 2
     log_var = frac * max_log + (1 - frac) * min_log
     x0 = pred_xstart_from_eps(x, eps, t_step, dtab)
+    if ddim:     # ddim_sample(eta=0), gaussian_diffusion.py:537-585: eps re-derived from the clamped x0, sigma = 0 (the draw is consumed)
+        c1 = torch.tensor(dtab.sqrt_recip_ac[t_step]).float()
+        c2 = torch.tensor(dtab.sqrt_recipm1_ac[t_step]).float()
+        eps2 = (c1 * x - x0) / c2
+        abp = torch.tensor(dtab.alphas_cumprod_prev[t_step]).float()
+        return x0 * torch.sqrt(abp) + torch.sqrt(1 - abp - 0.0) * eps2, x0
     mean = torch.tensor(dtab.posterior_mean_coef1[t_step]).float() * x0 + torch.tensor(dtab.posterior_mean_coef2[t_step]).float() * x
     nonzero = 0.0 if t_step == 0 else 1.0
     return mean + nonzero * torch.exp(0.5 * log_var) * noise, x0
@@ -347,7 +355,7 @@ def restore_dps_y0(sd, hp, cfg: LoopConfig, y, noise_fn: Callable, y_label=None,
         if not yt_mode:
             x = x.requires_grad_()
         t_step = find_nearest(dt.reduced, st["curr_sigma"] * 255 / 255.0)
-        xt, x0 = p_sample_prev_and_start(sd, hp, x, t_step, dtab, noise_fn(x), y_label)
+        xt, x0 = p_sample_prev_and_start(sd, hp, x, t_step, dtab, noise_fn(x), y_label, ddim=cfg.ddim_sample)
         if trace is not None:
             trace.append(("x0", t_i, x0.detach().clone()))
         if not st["last"] and yt_mode:

@@ -115,7 +115,7 @@ def restore_live(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_l
             if 'DPS' in gen_mode:                                          # main_ddpir.py:370-373
                 x = x.requires_grad_()
                 xt, x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_x_prev_and_start',
-                                              model_diffusion=model, diffusion=diffusion, ddim_sample=False,
+                                              model_diffusion=model, diffusion=diffusion, ddim_sample=getattr(cfg, "ddim_sample", False),
                                               alphas_cumprod=alphas_cumprod, **model_kwargs)
             else:
                 x0 = utils_model.model_fn(x, noise_level=curr_sigma * 255, model_out_type='pred_xstart',

@@ -82,3 +82,98 @@ def test_shard_ranges_partition_the_batch():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[i][1] == r[i + 1][0] for i in range(w - 1))
             assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+class _FakeLib:
+    """Stands in for libdiffpir_hip.so's two communicator entry points: records what dpir_comm_init receives."""
+
+    def __init__(self, fail_id):
+        self.fail_id, self.joined = fail_id, None
+
+    def dpir_comm_unique_id(self, buf):
+        if self.fail_id:
+            return -5
+        buf.raw = bytes(range(128))
+        return 0
+
+    def dpir_comm_init(self, h, world, rank, buf):
+        self.joined = (world, rank, bytes(buf.raw))
+        return 0
+
+    def dpir_last_error(self, h):
+        return b"librccl.so cannot be loaded"
+
+
+class _FakeEngine:
+    h = None
+
+    def __init__(self, fail_id=False):
+        self.lib = _FakeLib(fail_id)
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(f"engine error {rc}")
+
+
+@pytest.mark.parametrize("rank0_fails", [False, True])
+def test_rccl_rendezvous_is_collective_and_bounded(rank0_fails, monkeypatch):
+    """dist.init_rccl (the TCP exchange of the ncclUniqueId) at world = 3 with in-process fake engines: every rank receives rank 0's
+    id -- or, when rank 0 cannot create one, every rank raises TOGETHER (the fallback to torch.distributed must be collective, round-3
+    advisor finding) instead of spinning on a dead port; a stray connection that does not introduce itself is ignored."""
+    import threading
+    import time
+    port = _free_port()
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("DIFFPIR_RENDEZVOUS_TIMEOUT", "20")
+    engines = [_FakeEngine(fail_id=rank0_fails and r == 0) for r in range(3)]
+    errors = {}
+
+    def run(r):
+        try:
+            ddist.init_rccl(engines[r], r, 3, port=port)
+        except Exception as ex:
+            errors[r] = ex
+    ths = [threading.Thread(target=run, args=(r,)) for r in range(3)]
+    t0 = time.monotonic()
+    ths[0].start()
+    time.sleep(0.2)
+    stray = socket.create_connection(("127.0.0.1", port), timeout=5)       # says nothing useful
+    stray.sendall(b"GET / HT")
+    stray.close()
+    for t in ths[1:]:
+        t.start()
+    for t in ths:
+        t.join(30)
+    assert not any(t.is_alive() for t in ths) and time.monotonic() - t0 < 15
+    if rank0_fails:
+        assert sorted(errors) == [0, 1, 2]
+        assert all(e.lib.joined is None for e in engines)
+    else:
+        assert not errors, errors
+        assert [e.lib.joined[:2] for e in engines] == [(3, 0), (3, 1), (3, 2)]
+        assert all(e.lib.joined[2] == bytes(range(128)) for e in engines)
+
+
+def test_rccl_rendezvous_times_out_when_rank0_never_listens(monkeypatch):
+    monkeypatch.setenv("MASTER_ADDR", "127.0.0.1")
+    monkeypatch.setenv("DIFFPIR_RENDEZVOUS_TIMEOUT", "1")
+    with pytest.raises(RuntimeError, match="not listening"):
+        ddist.init_rccl(_FakeEngine(), 1, 2, port=_free_port())
+
+
+def test_dps_y0_sharding_needs_the_in_loop_allreduce():
+    """DPS_y0 couples the images of a batch through the batch-wide norm (round-3 advisor finding): sharded runs are refused unless the
+    engine carries the C ABI's RCCL communicator (the loop all-reduces the squared sums) and every rank has images."""
+    from diffpir_amd import restore
+
+    class E:
+        rccl = False
+    cfg = restore.LoopConfig(task="sr", sf=4, generate_mode="DPS_y0")
+    ddist.check_dps_sharding(E(), cfg, 8, 1)                                   # one rank: nothing to exchange
+    ddist.check_dps_sharding(E(), restore.LoopConfig(task="sr", sf=4, generate_mode="DPS_yt"), 8, 2)      # the norm cancels in DPS_yt
+    with pytest.raises(NotImplementedError, match="rccl"):
+        ddist.check_dps_sharding(E(), cfg, 8, 2)
+    E.rccl = True
+    ddist.check_dps_sharding(E(), cfg, 8, 2)
+    with pytest.raises(NotImplementedError, match="every rank"):
+        ddist.check_dps_sharding(E(), cfg, 1, 2)

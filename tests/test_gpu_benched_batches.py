@@ -1,0 +1,88 @@
+"""-m gpu: parity at the batches bench.py actually runs for BASELINE configs[2] (ImageNet-256 topology, B = 32) and configs[3]'s per-GPU
+share (FFHQ topology, motion PSF, B = 32).  The conv7 / conv6 dispatch (`blocks < 384`, csrc/conv6.hip), the split-K factors and
+the fused low-resolution prologue's workgroup count all depend on B, so the kernels the bench times are only exercised at these
+batches (round-3 review: only configs[1]'s B = 16 had such tests).  Oracle on a subset of the images + invariance against the same
+engine at a small batch; everything through the C ABI."""
+import numpy as np
+import pytest
+import torch
+
+import diffpir_amd
+from diffpir_amd import restore, synth
+from oracle import unet_oracle as uo, diffpir_oracle as do
+from tests import gpu_common
+from tests.gpu_common import make_model, seeded_noise_fn_np, rel_err, fft_prox_parity
+
+pytestmark = pytest.mark.gpu
+TOL_LAYER = 2e-5
+
+
+def _forward_at_batch(e, sd, hp, B, seed, probe, pair, key, precision):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((B, 3, 256, 256), generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    out = e.unet_forward(e.to_device(x.numpy()), t.numpy()).numpy()
+    worst = 0.0
+    for i in probe:
+        k = f"{key}_{i}"
+        if k not in gpu_common._ORACLE_CACHE:
+            gpu_common._ORACLE_CACHE[k] = uo.unet_forward(sd, hp, x[i:i + 1], t[i:i + 1]).numpy()
+        worst = max(worst, rel_err(out[i:i + 1], gpu_common._ORACLE_CACHE[k]))
+    lo, hi = pair
+    out2 = e.unet_forward(e.to_device(x[lo:hi].numpy()), t[lo:hi].numpy()).numpy()
+    inv = rel_err(out[lo:hi], out2)
+    print(f"{key} 256^2 forward B={B} [{precision}]: worst rel err vs oracle (images {probe}) {worst:.3e}; B={B} vs B={hi - lo} on images "
+          f"{lo}-{hi - 1} {inv:.3e}")
+    assert worst < TOL_LAYER and inv < TOL_LAYER
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f32"])
+def test_c3_imagenet256_forward_at_the_benched_batch_b32(precision):
+    """configs[2] as benched (`config_c3`): ImageNet-256 topology at 256^2, B = 32, a different timestep per image."""
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision(precision)
+        hp = uo.imagenet256_hp()
+        model, sd = make_model(e, hp)
+        _forward_at_batch(e, sd, hp, 32, 91, (5, 31), (20, 22), "c3_b32", precision)
+    finally:
+        e.close()
+
+
+@pytest.fixture(scope="module", params=["f16x3", "f32"])
+def ffhq(request):
+    e = diffpir_amd.Engine(0)
+    e.set_precision(request.param)
+    model, sd = make_model(e, uo.ffhq_hp())
+    yield e, sd, request.param
+    e.close()
+
+
+def test_c4_ffhq_forward_at_the_per_gpu_batch_b32(ffhq):
+    """configs[3]'s per-GPU share (32 of 256 images): FFHQ topology forward at B = 32."""
+    e, sd, precision = ffhq
+    _forward_at_batch(e, sd, uo.ffhq_hp(), 32, 92, (0, 17, 31), (30, 32), "c4_b32", precision)
+
+
+def test_c4_motion_loop_at_the_per_gpu_batch_b32_4nfe(ffhq):
+    """configs[3] per GPU: 32 images, one non-symmetric 61x61 motion PSF per image, 4 NFE through the replayed graph, host noise
+    drawn for the whole batch in the reference's order; the oracle restores images 7 and 30 with the same per-image noise slices."""
+    e, sd, precision = ffhq
+    B, sub = 32, [7, 30]
+    case = synth.make_case("deblur", B, 256, 256, seed=17, ksize=61, blur="motion")
+    cfg = restore.LoopConfig(task="deblur", iter_num=4, lambda_=7.0, zeta=0.3)
+    out = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=seeded_noise_fn_np(67),
+                                use_graph=True).numpy()
+
+    def sliced(seed):
+        g = torch.Generator().manual_seed(seed)
+        return lambda like: torch.randn((B,) + tuple(like.shape[1:]), generator=g, dtype=torch.float32)[sub]
+    key = "c4_b32_4nfe"
+    if key not in gpu_common._ORACLE_CACHE:
+        ocfg = do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3)
+        ty, tk = torch.from_numpy(case["y"][sub]), torch.from_numpy(case["k"][sub])
+        ref = do.restore(sd, uo.ffhq_hp(), ocfg, ty, k=tk, noise_fn=sliced(67)).numpy()
+        exact = do.restore(sd, uo.ffhq_hp(), ocfg, ty, k=tk, noise_fn=sliced(67), exact_prox=True).numpy()
+        gpu_common._ORACLE_CACHE[key] = (ref, exact)
+    ref, exact = gpu_common._ORACLE_CACHE[key]
+    fft_prox_parity(out[sub], ref, case["gt"][sub], f"C4 motion B=32 4-NFE, images 7 and 30 [{precision}] vs oracle", exact=exact)

@@ -150,3 +150,78 @@ def test_bench_launch_line_two_ranks_on_one_gpu_gloo():
     line = json.loads(lines[0])
     assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 4 and line["scaling"] == "weak" and line["value"] > 0
     assert line["roofline"]["frac"] > 0 and line["cpu_baseline"] is None
+
+
+# ---- N > 1 ranks on N devices through the DEFAULT collective (RCCL over xGMI, bound by the C ABI).  These run the moment a box shows
+# ---- two GPUs and skip -- naming the device count -- on the one-GPU boxes this project has had so far (main_ddpir.py:135).
+
+def _need_two_devices():
+    from diffpir_amd.engine import device_count
+    n = device_count()
+    if n < 2:
+        pytest.skip(f"RCCL with two ranks needs two GPUs: dpir_device_count() = hipGetDeviceCount() = {n} on this box "
+                    f"(ncclCommInitRank(world=2) / the TCP unique-id exchange of dist.init_rccl stay unexecuted here)")
+    return n
+
+
+def _run_rccl(rank, world, port, n, ret):
+    """One rank of the product launch: device = LOCAL_RANK, dist.init('rccl') -> attach (unique id over TCP, ncclCommInitRank) ->
+    restore_sharded (ncclAllGather of engine-owned uint8 buffers on the engine stream)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HSA_ENABLE_IPC_MODE_LEGACY="0")
+    os.environ.pop("DIFFPIR_COLLECTIVE", None)
+    import diffpir_amd
+    from diffpir_amd import dist as ddist, restore
+    from oracle import unet_oracle as uo
+    from tests.gpu_common import make_model
+    r, lr, w = ddist.init("rccl")
+    eng = diffpir_amd.Engine(lr)
+    ddist.attach(eng)
+    if w > 1:
+        assert "C ABI" in ddist.collective_name(), ddist.collective_name()       # no silent fallback to torch.distributed
+    make_model(eng, uo.tiny_hp())
+    cfg = restore.LoopConfig(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3)
+    case = _case(n)
+    u8, _ = ddist.restore_sharded(eng, cfg, case["y"], k=case["k"], rank=r, world=w, image_offset=100, seed=9, use_graph=True,
+                                  noise_source="device")
+    ddist.barrier()
+    assert ddist.max_over_ranks(float(r)) == float(w - 1)
+    ret[rank] = u8.numpy().tobytes()
+    ddist.shutdown()
+    eng.close()
+
+
+@pytest.mark.parametrize("n", [4, 3])
+def test_rccl_two_ranks_two_devices(n):
+    """Gathered uint8 batch of two ranks on devices 0 / 1 == the one-rank result, bit for bit (even and ragged shards)."""
+    _need_two_devices()
+    import torch.multiprocessing as mp
+    mgr = mp.Manager()
+    one, two = mgr.dict(), mgr.dict()
+    mp.spawn(_run_rccl, args=(1, _free_port(), n, one), nprocs=1, join=True)
+    mp.spawn(_run_rccl, args=(2, _free_port(), n, two), nprocs=2, join=True)
+    assert len(one[0]) == n * 32 * 32 * 3
+    assert two[0] == one[0] and two[1] == one[0]
+
+
+def test_bench_launch_line_two_ranks_two_devices_c4():
+    """The driver's N = 2 launch line on the default collective: BASELINE configs[3]'s per-GPU work (c4: FFHQ topology, motion PSF,
+    32 images per GPU), shortened to 6 NFE."""
+    _need_two_devices()
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for v in ("DIFFPIR_COLLECTIVE", "DIFFPIR_BENCH_BACKEND", "DIFFPIR_BENCH_DEVICE"):
+        env.pop(v, None)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--config", "c4", "--steps", "1", "--warmup", "1",
+           "--nfe", "6"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["global_batch"] == 64 and line["value"] > 0
+    assert "C ABI" in line["config"]["collective"]

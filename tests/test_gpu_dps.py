@@ -136,6 +136,33 @@ def test_dps_y0_loop_matches_live_reference_fixture(golden, precision):
         e.close()
 
 
+def test_dps_y0_loop_full_size_ffhq_vs_oracle():
+    """generate_mode 'DPS_y0' at the benched topology and size (round-3 review: the loop was pinned on the tiny topology at 64^2 only):
+    FFHQ topology, 64^2 -> 256^2 (x4, Resizer), B = 2, 5 NFE, host noise.  Against oracle.restore_dps_y0 (torch.autograd through the
+    oracle network, which is bit-identical to the live reference network): psample_kernel, band_resample_T_kernel, the batch-wide fp64
+    norm and the run-time-scaled f16 dgrad over 65536-pixel planes."""
+    from diffpir_amd import synth
+    hp = uo.ffhq_hp()
+    e, sd = _engine(hp, "f16x3")
+    try:
+        case = synth.make_case("sr", 2, 256, 256, seed=31, sf=4)
+        cfg = restore.LoopConfig(task="sr", iter_num=5, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+        out = restore.restore_batch(e, cfg, case["y"], noise_source="host", noise_fn=seeded_noise_fn_np(81)).numpy()
+        torch.set_num_threads(32)
+        gen = torch.Generator().manual_seed(81)
+        ocfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+        ref = do.restore_dps_y0(sd, hp, ocfg, torch.from_numpy(case["y"]),
+                                noise_fn=lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)).numpy()
+        err = float(np.abs(out - ref).max())
+        gt = case["gt"] * 2 - 1
+        gap = abs(restore.psnr_batch(out * 2 - 1, gt) - restore.psnr_batch(ref * 2 - 1, gt))
+        print(f"DPS_y0 FFHQ topology 256^2 B=2 5-NFE [f16x3] vs oracle autograd: max|diff| {err:.3e} (output range {np.abs(ref).max():.2f}), "
+              f"|dPSNR| {gap:.2e} dB")
+        assert gap <= 1e-3 and err < 2e-4 * max(1.0, float(np.abs(ref).max()))
+    finally:
+        e.close()
+
+
 def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
     """The two gradient modes that need no network backward: DPS_yt (main_ddpir.py:439-445) and the first-order data step of the
     DiffPIR loop (sub_1_analytic: false, :420-430; replayed step graph), task sr x4, against the reference's own runs."""
@@ -158,6 +185,81 @@ def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
             err = float(np.abs(out - g["fo_out"]).max())
             print(f"first-order data step, graph={graph}, vs LIVE reference: max|diff| {err:.3e} (output range {np.abs(g['fo_out']).max():.2f})")
             assert err < 1e-4
+    finally:
+        e.close()
+
+
+def test_model_fn_other_output_types_match_live_reference_fixture(golden):
+    """utils_model.model_fn(..., model_out_type = 'pred_x_prev_and_start' | 'pred_x_prev' | 'epsilon' | 'score') with p_sample and with
+    ddim_sample(eta=0) (utils/utils_model.py:219-258 over dpir_p_sample / dpir_eps_from_xstart) against the live reference's outputs
+    for the same randn_like tensor (tests/golden/model_fn_types.npz)."""
+    from diffpir_amd import utils_model, script_util, schedule
+    g = golden("model_fn_types")
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision("f16x3")
+        model, _ = make_model(e, uo.tiny_hp())
+        diffusion = script_util.create_gaussian_diffusion(steps=1000, learn_sigma=True)
+        dt = schedule.DriverTables.make()
+        x = e.to_device(g["x"])
+        utils_model.set_randn_like(lambda like: e.to_device(g["noise"]))
+        try:
+            for j, sig in enumerate(g["noise_levels"]):
+                for ddim in (False, True):
+                    tag = f"{j}_{'ddim' if ddim else 'psample'}"
+                    kw = dict(noise_level=float(sig) * 255, model_diffusion=model, diffusion=diffusion, ddim_sample=ddim, alphas_cumprod=dt.alphas_cumprod)
+                    xt, x0 = utils_model.model_fn(x, model_out_type="pred_x_prev_and_start", **kw)
+                    errs = {"x0": rel_err(x0.numpy(), g[f"x0_{tag}"]), "xt": rel_err(xt.numpy(), g[f"xt_{tag}"]),
+                            "pred_x_prev": rel_err(utils_model.model_fn(x, model_out_type="pred_x_prev", **kw).numpy(), g[f"xt_{tag}"])}
+                    for typ in ("epsilon", "score"):
+                        errs[typ] = rel_err(utils_model.model_fn(x, model_out_type=typ, **kw).numpy(), g[f"{typ}_{tag}"])
+                    print(f"model_fn output types, noise level {float(sig):.2f}, {'ddim' if ddim else 'p_sample'}: rel err vs LIVE reference "
+                          + ", ".join(f"{k} {v:.2e}" for k, v in errs.items()))
+                    # x0 is clamped to [-1, 1]; epsilon / score divide the x0 error by sqrt(1 - alpha_bar) (0.05 at the low level)
+                    assert max(errs.values()) < 5e-5, errs
+            with pytest.raises(ValueError):
+                utils_model.model_fn(x, model_out_type="xstart", **kw)
+        finally:
+            utils_model.set_randn_like(None)
+        # the default draw (no hook): the engine's Philox stream, a fresh stream id per call
+        kw["ddim_sample"] = False
+        a = utils_model.model_fn(x, model_out_type="pred_x_prev", **kw).numpy()
+        b = utils_model.model_fn(x, model_out_type="pred_x_prev", **kw).numpy()
+        assert np.isfinite(a).all() and np.abs(a - b).max() > 1e-3
+    finally:
+        e.close()
+
+
+@pytest.mark.parametrize("mode", ["DPS_y0", "DPS_y0+ddim", "DPS_yt", "first_order"])
+def test_stepwise_plug_loops_equal_the_monolithic_loops(golden, mode):
+    """The reference's loop body written against the plugs (restore_batch_stepwise: model_fn 'pred_x_prev_and_start', Resizer,
+    grad_and_value and the loop's own expressions on device arrays -- main_ddpir.py:370-373, 420-445) gives the SAME result as
+    dpir_run_dps_loop / dpir_run_loop, bit for bit, and both match the live-reference fixtures."""
+    from diffpir_amd import script_util
+    g, gt2 = golden("dps"), golden("model_fn_types")
+    hp = uo.tiny_hp()
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision("f16x3")
+        e.enable_grad()
+        model, sd = make_model(e, hp)
+        cfgs = {"DPS_y0": (restore.LoopConfig(task="sr", iter_num=int(g["dps_nfe"]), lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0"),
+                           g["dps_y"], int(g["dps_seed"]), g["dps_out"], 2e-4),
+                "DPS_y0+ddim": (restore.LoopConfig(task="sr", iter_num=int(gt2["dpsddim_nfe"]), lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic",
+                                                   generate_mode="DPS_y0", ddim_sample=True),
+                                gt2["dpsddim_y"], int(gt2["dpsddim_seed"]), gt2["dpsddim_out"], 2e-4),
+                "DPS_yt": (restore.LoopConfig(task="sr", iter_num=10, lambda_=600.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0),
+                           g["dps_y"], int(g["dpsyt_seed"]), g["dpsyt_out"], 1e-4 * max(1.0, float(np.abs(g["dpsyt_out"]).max()))),
+                "first_order": (restore.LoopConfig(task="sr", iter_num=6, lambda_=6.0e5, zeta=0.25, sf=4, sr_mode="cubic", sub_1_analytic=False),
+                                g["dps_y"], int(g["fo_seed"]), g["fo_out"], 1e-4)}
+        cfg, y, seed, ref, tol = cfgs[mode]
+        mono = restore.restore_batch(e, cfg, y, noise_source="host", noise_fn=seeded_noise_fn_np(seed)).numpy()
+        diffusion = script_util.create_gaussian_diffusion(steps=1000, learn_sigma=True)
+        step = restore.restore_batch_stepwise(model, diffusion, cfg, e.to_device(y), noise_fn=seeded_noise_fn_np(seed)).numpy()
+        err = float(np.abs(step - ref).max())
+        print(f"{mode}: stepwise plugs vs monolithic loop max|diff| {float(np.abs(step - mono).max()):.3e}; stepwise vs LIVE reference {err:.3e}")
+        assert np.array_equal(step, mono)
+        assert err < tol
     finally:
         e.close()
 

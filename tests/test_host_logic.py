@@ -84,6 +84,20 @@ def test_struct_layouts_match_header():
     assert C.sizeof(_lib.Step) == 48
     assert C.sizeof(_lib.UNetDesc) == 4 * 7 + 32 + 4 + 32 + 4
     assert _lib.LoopDesc.y_dev.offset == 48
+    # every struct of the header, as a C compiler lays it out, against the ctypes mirror
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("gcc"):
+        pairs = [("dpir_unet_desc", _lib.UNetDesc), ("dpir_tensor", _lib.Tensor), ("dpir_step", _lib.Step), ("dpir_loop_desc", _lib.LoopDesc),
+                 ("dpir_dps_coef", _lib.DpsCoef), ("dpir_psample_coef", _lib.PSampleCoef), ("dpir_degrade_desc", _lib.DegradeDesc)]
+        with tempfile.TemporaryDirectory() as td:
+            src = os.path.join(td, "sz.c")
+            open(src, "w").write('#include "diffpir_engine.h"\n#include <stdio.h>\nint main(void){' +
+                                 "".join(f'printf("%zu\\n", sizeof({c}));' for c, _ in pairs) + "return 0;}\n")
+            subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), src, "-o", os.path.join(td, "sz")], check=True)
+            sizes = [int(v) for v in subprocess.run([os.path.join(td, "sz")], check=True, capture_output=True, text=True).stdout.split()]
+        assert sizes == [C.sizeof(t) for _, t in pairs], list(zip([c for c, _ in pairs], sizes, [C.sizeof(t) for _, t in pairs]))
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")

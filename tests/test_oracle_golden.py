@@ -172,6 +172,41 @@ def test_model_fn_pred_xstart_ddim_flag_is_a_no_op(golden):
         assert np.abs(x0 - g[f"x0_{j}_psample"]).max() < 1e-5
 
 
+def test_model_fn_other_output_types_and_ddim_dps_loop_match_live_reference(golden):
+    """Live-reference model_fn 'pred_x_prev_and_start' (p_sample with the learned-range variance and ddim_sample(eta=0)) and the
+    DPS_y0 loop with config.ddim_sample: the oracle restatement (p_sample_prev_and_start(ddim=...)) reproduces both; the host-side
+    ddim coefficients of diffpir_amd.schedule are the float32 values the reference computes."""
+    import torch
+    from diffpir_amd import schedule
+    g = golden("model_fn_types")
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    dt, dtab = do.DriverTables(), do.DiffusionTables()
+    x, noise = torch.from_numpy(g["x"]), torch.from_numpy(g["noise"])
+    tab = schedule.DiffusionTables.make()
+    for j, sig in enumerate(g["noise_levels"]):
+        t = do.find_nearest(dt.reduced, float(sig) * 255 / 255.0)
+        for ddim in (False, True):
+            tag = f"{j}_{'ddim' if ddim else 'psample'}"
+            with torch.no_grad():
+                xt, x0 = do.p_sample_prev_and_start(sd, hp, x, t, dtab, noise, ddim=ddim)
+            assert np.abs(x0.numpy() - g[f"x0_{tag}"]).max() < 1e-5
+            assert np.abs(xt.numpy() - g[f"xt_{tag}"]).max() < 2e-5
+            # 'epsilon' / 'score' (utils_model.py:247-255) from the fixture's own x0 with the driver's float32 table
+            a_t = torch.as_tensor(dt.alphas_cumprod)[t]
+            eps = (x - a_t ** 0.5 * torch.from_numpy(g[f"x0_{tag}"])) / (1 - a_t) ** 0.5
+            assert np.array_equal(eps.numpy(), g[f"epsilon_{tag}"])
+            assert np.array_equal((-eps / (1 - a_t) ** 0.5).numpy(), g[f"score_{tag}"])
+        sa, s1m = tab.ddim_coef(t)
+        abp = torch.tensor(tab.alphas_cumprod_prev[t]).float()
+        assert float(sa) == float(torch.sqrt(abp)) and float(s1m) == float(torch.sqrt(1 - abp - 0.0))
+    gen = torch.Generator().manual_seed(int(g["dpsddim_seed"]))
+    cfg = do.LoopConfig("sr", int(g["dpsddim_nfe"]), 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0", ddim_sample=True)
+    out = do.restore_dps_y0(sd, hp, cfg, torch.from_numpy(g["dpsddim_y"]),
+                            noise_fn=lambda like: torch.randn(like.shape, generator=gen, dtype=torch.float32)).numpy()
+    assert np.abs(out - g["dpsddim_out"]).max() < 2e-5
+
+
 @pytest.mark.parametrize("mode", ["repaint", "vanilla"])
 def test_inpaint_generate_modes_match_live_reference(golden, mode):
     """main_ddpir.py:349-358 (repaint conditioning before the denoiser), :385 (no prox outside DiffPIR mode), :448 (re-noise)."""
