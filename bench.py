@@ -44,7 +44,7 @@ PEAK_HBM_TBS = 8.0               # HBM3E spec
 PROX_BYTES_PER_IMAGE = {1: 2_497_536, 4: 2_761_728}     # sf = 1 / sf = 4
 # HBM-side bytes per launch of the roofline kernel classes from the committed PMC passes (bench.py cannot run rocprofv3 on
 # itself): profiles/pmc_traffic.json is written by tools/pmc_traffic.py from profiles/r03/*_pmc_{FETCH,WRITE}_SIZE.txt (commands:
-# tools/gpu_prof_r3.sh; FETCH_SIZE doubled per the gfx950 note).
+# tools/gpu_prof_round.sh; FETCH_SIZE doubled per the gfx950 note).
 PMC_TRAFFIC = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))) if os.path.exists(os.path.join(ROOT, "profiles", "pmc_traffic.json")) else {}
 
 
@@ -123,7 +123,7 @@ def conv_roofline(eng, B, H, precision, model_name):
     peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x1": 2500.0}.get(precision, PEAK_F16X3_TFLOPS)
     kern = ("conv2_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32, exact fp32)" if precision == "f32" else
             "conv6_mfma_kernel<3x3, X1> (one v_mfma_f32_32x32x16_f16 per product, hi planes only; two workgroups per CU)" if precision == "f16x1" else
-            "3x3 class: conv7_mfma_kernel (whole-K launches of the 8x32 geometry) + conv6_mfma_kernel (split-K, 16x16 / 8x8) "
+            "3x3 class: conv7_mfma_kernel<geometry, f16x3> (64 co x 128 px per wave, weights straight into registers; + conv6_mfma_kernel for the split-K launches of the 8x32 geometry and the 128->6 output convolution) "
             "(3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split*_kernel; two workgroups per CU)")
     step_fl = eng.unet_flops(H, H) * B
     tr = PMC_TRAFFIC.get(f"{model_name}_B{B}_{H}_{precision}")
@@ -341,19 +341,31 @@ def main():
         eg.enable_grad()
         mg = script_util.create_model(**weights.create_model_kwargs(weights.model_hp("ffhq")), engine=eg)
         mg.load_state_dict(weights.synth_state_dict(weights.model_hp("ffhq"), 0))
-        Bd, nfe_d = 8, 6
-        cd = synth.make_case("sr", Bd, 256, 256, seed=400, sf=4)
-        cfgd = restore.LoopConfig(task="sr", iter_num=nfe_d, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
-        yd_ = eg.to_device(cd["y"])
-        restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)          # allocations
-        ta = time.perf_counter()
-        od = restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)
-        eg.sync()
-        td = time.perf_counter() - ta
+        peak_d = PEAK_FP32_MFMA_TFLOPS if args.precision == "f32" else PEAK_F16X3_TFLOPS
+        fl_img = eg.unet_flops(256, 256)                      # one forward; the input-gradient pass runs the same contractions transposed
+        nfe_d = 6
+
+        def dps_at(Bd):
+            cd = synth.make_case("sr", Bd, 256, 256, seed=400, sf=4)
+            cfgd = restore.LoopConfig(task="sr", iter_num=nfe_d, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+            yd_ = eg.to_device(cd["y"])
+            restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)          # allocations
+            ta = time.perf_counter()
+            od = restore.restore_batch(eg, cfgd, yd_, noise_source="device", seed=1)
+            eg.sync()
+            td = (time.perf_counter() - ta) / (nfe_d - 1)
+            ach = 2.0 * fl_img * Bd / td / 1e12
+            return {"batch": Bd, "ms_per_nfe": round(td * 1e3, 2), "images_per_s_at_100_nfe": round(Bd / (td * 100), 4),
+                    "finite": bool(np.isfinite(od.numpy()).all()),
+                    "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": round(peak_d, 1), "unit": "TFLOP/s", "frac": round(ach / peak_d, 4),
+                                 "flops_per_nfe": 2.0 * fl_img * Bd}}
+        d8, d16 = dps_at(8), dps_at(16)
         dps = {"what": "generate_mode DPS_y0 (main_ddpir.py:370-373, 434-438), FFHQ topology, x4 SISR 64^2 -> 256^2: per NFE one UNet forward "
-                       f"({args.precision}), p_sample, residual norm, Resizer^T and one UNet input-gradient pass (dgrad on the same MFMA kernels as the forward); eager launches",
-               "batch": Bd, "nfe": nfe_d, "ms_per_nfe": round(td / (nfe_d - 1) * 1e3, 2),
-               "images_per_s_at_100_nfe": round(Bd / (td / (nfe_d - 1) * 100), 4), "finite": bool(np.isfinite(od.numpy()).all())}
+                       f"({args.precision}), p_sample, residual norm, Resizer^T and one UNet input-gradient pass (dgrad on the same MFMA kernels as the forward: "
+                       "conv7 with the flipped / transposed weight pack and a run-time power-of-two scale on dY); eager launches.  roofline: the "
+                       "algorithmic FLOPs of forward + input-gradient pass (2 x the forward's: every contraction runs once each way) over the whole NFE "
+                       "(every kernel and launch gap) against the same MFMA peak as the headline",
+               "nfe": nfe_d, **{k: v for k, v in d8.items()}, "at_batch_16": d16}
         eg.close()
 
     # ---- secondary measurements in the other arithmetic modes (same inputs, weights, device noise and graph path)

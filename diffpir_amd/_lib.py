@@ -144,11 +144,10 @@ def load_debug():
     d.dpir_debug_victim_alu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
     for fn in (d.dpir_debug_victim_fft_pk, d.dpir_debug_victim_fft_nopk):
         fn.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
-    d.dpir_debug_conv7_check.argtypes = [C.c_void_p] + [C.c_int] * 7 + [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong), C.POINTER(C.c_float)]
-    d.dpir_debug_conv7x_check.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
-                                                                         C.POINTER(C.c_float), C.POINTER(C.c_int)]
+    d.dpir_debug_conv7_check.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_ulonglong),
+                                                                        C.POINTER(C.c_float), C.POINTER(C.c_int)]
     for n in ("dpir_debug_conv_bench", "dpir_debug_victim", "dpir_debug_victim_alu", "dpir_debug_victim_fft_pk", "dpir_debug_victim_fft_nopk",
-              "dpir_debug_conv7_check", "dpir_debug_conv7x_check"):
+              "dpir_debug_conv7_check"):
         getattr(d, n).restype = C.c_int
     _dbg = d
     return d

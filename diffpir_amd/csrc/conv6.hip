@@ -592,24 +592,16 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, Pendi
         k.stat = a.stat; k.stat_slots = conv6_stat_slots(a.H, a.W);
         if (stat_kind_out) *stat_kind_out = 1;
     }
-    // conv7 (same results bit for bit, 7-14 % faster: fewer LDS reads, weights straight into registers) takes the launches it is built
-    // for: 8 x 32 geometry, whole K in one workgroup, full 128-channel output blocks (it has no idle-wave path), f16x3, no run-time
-    // output scale.  DPIR_CONV7=0 switches it off (A/B).
-    static const bool conv7_on = !(getenv("DPIR_CONV7") && atoi(getenv("DPIR_CONV7")) == 0);
-    const bool can7 = geo == 0 && S == 1 && !a.x1 && !a.out_scale_dev && a.Cout % 128 == 0;
-    if (a.force_kernel == 7 && !can7) return invalid("conv6: conv7 was forced for a launch it does not take");
-    if (can7 && a.force_kernel != 6 && (conv7_on || a.force_kernel == 7)) {
-        DPIR_TRY(launch_conv7(s, k, blocks));
-        DPIR_HIP(hipGetLastError());
-        return Status{};
-    }
-    if (a.x1) {
-        if (geo == 0) DPIR_TRY((launch6<0, 4, true>(s, k, blocks * S)));
-        else if (geo == 1) DPIR_TRY((launch6<1, 4, true>(s, k, blocks * S)));
-        else DPIR_TRY((launch6<2, 3, true>(s, k, blocks * S)));
-    } else if (geo == 0) DPIR_TRY((launch6<0, 4, false>(s, k, blocks * S)));
-    else if (geo == 1) DPIR_TRY((launch6<1, 4, false>(s, k, blocks * S)));
-    else DPIR_TRY((launch6<2, 3, false>(s, k, blocks * S)));
+    // conv7 (csrc/conv7.hip: same results bit for bit) is the 3x3 kernel; conv6 keeps the two launch classes of the 8 x 32 geometry it
+    // is measurably faster at (profiles/r04/conv7x_check.log): split-K launches (x1.07) and a last co-block with at most 64 live
+    // channels (x1.05) -- unless the whole launch has at most 32 output channels (the 128 -> 6 output convolution), which conv7's
+    // NARROW variant spreads over all four waves.  force_kernel (tests): 6 = conv6 (geometry 0 only), 7 = conv7.
+    const bool idle_half = (a.Cout & 127) != 0 && (a.Cout & 127) <= 64 && a.Cout > 32;
+    const bool use6 = a.force_kernel == 6 || (a.force_kernel != 7 && geo == 0 && (S > 1 || idle_half));
+    if (use6 && geo != 0) return invalid("conv6 is built for the 8 x 32 geometry only (conv7 has the 16 x 16 and 8 x 8 ones)");
+    if (!use6) DPIR_TRY(launch_conv7(s, k, blocks * S, a.x1));
+    else if (a.x1) DPIR_TRY((launch6<0, 4, true>(s, k, blocks * S)));
+    else DPIR_TRY((launch6<0, 4, false>(s, k, blocks * S)));
     if (S > 1) {
         PendingConv pc;
         pc.partial = k.partial; pc.ksplit = S; pc.bias = k.bias; pc.res = k.res; pc.res_mode = k.res_mode; pc.out = k.out;

@@ -18,7 +18,8 @@ struct Conv6K {
     float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
 };
 
-// conv7.hip: the geometry-0 (W >= 32), whole-K, f16x3 case of launch_conv6 with the workgroup tile cut as 64 co x 128 px per wave
-Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks);
+// conv7.hip: every case of launch_conv6 (all three geometries, split-K slabs, f16x1, dgrad scale) with the workgroup tile cut as
+// 64 co x 128 px per wave; blocks = pixel tiles x co-blocks x ksplit
+Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks, bool x1);
 
 }  // namespace dpir

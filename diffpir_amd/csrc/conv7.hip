@@ -1,23 +1,25 @@
-// conv7: the geometry-0 (W >= 32), whole-K, f16x3 case of the 3x3 convolution with the workgroup tile cut the other way (round 3).
+// conv7: the 3x3 convolution of the f16x3 / f16x1 modes (round 3: geometry 0 only; round 4: every case -- the 16 x 16 and 4-image 8 x 8
+// geometries, split-K partial slabs, f16x1, the run-time output scale of dgrad, idle co-halves).
 //
-// Same arithmetic, operand planes, weight pack and workgroup tile as conv6 (128 output channels x 256 pixels = 8 rows x 32 columns,
-// f16x3: al*bh, ah*bl, ah*bh per product, in that order per accumulator -> the outputs and the fused GroupNorm sums are BIT-IDENTICAL
-// to conv6's; tools/conv7_check.py asserts it), but inside the workgroup
+// Same arithmetic, operand planes, weight pack and workgroup tile as conv6 (128 output channels x 256 pixels; f16x3: al*bh, ah*bl,
+// ah*bh per product, in that order per accumulator -> outputs, fused GroupNorm sums and split-K slabs are BIT-IDENTICAL to conv6's:
+// 16 shape x residual x mode cases, profiles/r04/conv7x_check.log), but inside the workgroup
 //   conv6: a wave owns 32 output channels x all 256 pixels  -> per tap 2 A + 16 B fragment reads from LDS for 24 MFMAs, and the
 //          weights (private to the wave) travel L2 -> LDS ring -> registers although no other wave reads them;
 //   conv7: a wave owns 64 output channels x 128 pixels      -> per tap 8 B fragment reads from LDS for 24 MFMAs; the 4 A fragments
 //          (2 co-tiles x hi / lo) are loaded STRAIGHT into registers (buffer_load_dwordx4: 16 B per lane IS the fragment, the host
 //          pack is in lane order already), two taps ahead, in a three-set register ring (9 taps % 3 == 0: the ring index is a
 //          compile-time constant of the unrolled chunk body).  LDS reads per MFMA 18/24 -> 8/24, LDS footprint 76 -> 44 KiB.
-//   Cost: the two waves that share a co-half request the same weights (L2 -> CU weight traffic doubles, 144 KiB per chunk and
-//   workgroup, all L2 hits) and the ring takes ~48 VGPRs (234 in all, still two workgroups per CU).
-// Measured against conv6 on the same operands (profiles/r03/conv7_prototype_check.log, back to back on one box): 128->128 @256^2
-// 807 -> 738 us, 256->128 @256^2 1441 -> 1351 us, 256->256 @128^2 745 -> 672 us, 512->512 @64^2 752 -> 661 us (x1.07 ... x1.14).
-// Split-K launches, the 16x16 / 8x8 geometries, f16x1 and the dgrad scale stay on conv6 (launch_conv6 decides).
+//   Cost: the two waves that share a co-half request the same weights (L2 -> CU weight traffic doubles, all L2 hits) and the ring
+//   takes ~48 VGPRs (214-234 in all, still two workgroups per CU).
+// Measured back to back against conv6 on one box (profiles/r04/conv7x_check.log): x1.03-1.06 at 256^2 / 128^2, x1.03 in f16x1 and with
+// the dgrad scale, x1.01-1.08 at 16 x 16 / 8 x 8 -- and x0.93 for the split-K launches of the 8 x 32 geometry, x0.95 for the 128 -> 6
+// output convolution (one live co-tile of four): those two launch classes stay on conv6 (launch_conv6 decides).  In the loop
+// (bench.py, DPIR_CONV7=1/0 interleaved in one call, profiles/r04/bench_ab_conv7_in_one_call.log): 8.34 vs 8.20 images/s.
+// PMC (profiles/r04): matrix pipe busy 78.1 % of the cycles at an effective 1.67 GHz (conv6: 74.8 % at 1.62 GHz).
 #include "common.h"
 #include "lds_dma.h"
 #include "conv6_params.h"
-#include <stdlib.h>
 #include <type_traits>
 
 namespace dpir {
@@ -38,31 +40,54 @@ __device__ __forceinline__ float dpp_row_shr7(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
 }
 
+template <int GEO> struct Geo7;
+template <> struct Geo7<0> { static constexpr int LTW = 5, LTH = 3, TI = 1; };   // 8 rows x 32 columns
+template <> struct Geo7<1> { static constexpr int LTW = 4, LTH = 4, TI = 1; };   // 16 x 16
+template <> struct Geo7<2> { static constexpr int LTW = 3, LTH = 3, TI = 4; };   // 4 images x 8 x 8
+
+// NARROW (8 x 32 geometry): a launch with at most 32 output channels (the 128 -> 6 output convolution, the 128 -> 3 dgrad of conv_in).  One
+// live co-tile: instead of two waves computing a dead second co-tile and two waves idling, all four waves take that co-tile for a
+// quarter of the pixels each (wave tile 32 co x 64 px, 6 MFMAs per tap instead of 24 on half the waves).
+template <int GEO, bool X1, bool NARROW>
 __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int TW = 32, TH = 8, LW = TW + 2, LH = TH + 2;
-    constexpr int PATCH = LH * LW;                      // 340 entries per k-half
-    constexpr int NPIECE = (2 * PATCH + 63) / 64;       // 11 one-KiB DMA pieces per plane
-    constexpr int NXT = (NPIECE + 3) / 4;               // 3 per wave and plane
-    constexpr int NACT = 2 * NXT;                       // activation DMA instructions per wave and chunk
+    using G = Geo7<GEO>;
+    constexpr int TW = 1 << G::LTW, TH = 1 << G::LTH, TI = G::TI, LW = TW + 2, LH = TH + 2;
+    constexpr int PATCH = TI * LH * LW;                 // entries per k-half
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;       // one-KiB DMA pieces per plane
+    constexpr int NXT = (NPIECE + 3) / 4;               // per wave and plane
+    constexpr int NPL = X1 ? 1 : 2;                     // operand planes (hi [, lo])
+    constexpr int NACT = NPL * NXT;                     // activation DMA instructions per wave and chunk
+    static_assert(NACT <= 8, "the activation pieces must be older than the weights of taps 7 and 8");
     constexpr int XB = NPIECE * 1024;
     constexpr int TAPS = 9;
+    constexpr int CT = NARROW ? 1 : 2;                  // co-tiles (32 channels) per wave
+    constexpr int TPG = NARROW ? 1 : 2;                 // pixel tiles (32 pixels) per group; a wave has two groups
+    static_assert(!NARROW || GEO == 0, "the narrow variant exists for the 8 x 32 geometry");
     extern __shared__ __attribute__((aligned(16))) char smem7[];      // [2 buffers][hi|lo][XB]; the epilogue slabs alias it
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int cw = wave & 1, pw = wave >> 1;            // co half (64 channels), pixel half (rows 4 pw .. 4 pw + 3)
+    // co half (64 channels), pixel half (rows 4 pw .. 4 pw + 3); NARROW: one co-tile, pixel quarter (rows 2 pw, 2 pw + 1)
+    const int cw = NARROW ? 0 : wave & 1, pw = NARROW ? wave : wave >> 1;
     const int l31 = lane & 31;
     const int half = lane >> 5;
 
     int bid = blockIdx.x;
     if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous tiles, as conv6
+    const int split = bid % p.ksplit;
+    bid /= p.ksplit;
     const int co_blk = bid % p.n_co_blocks;
     const int ptile = bid / p.n_co_blocks;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
-    const int n0 = ptile / tiles_per_img;
-    const int trem = ptile - n0 * tiles_per_img;
+    const int img_grp = ptile / tiles_per_img;
+    const int n0 = img_grp * TI;
+    const int trem = ptile - img_grp * tiles_per_img;
+    const int ch_begin = split * p.chunks_per_split;
+    const int ch_end = min(p.n_chunks_total, ch_begin + p.chunks_per_split);
+    const int co_wave = co_blk * 128 + cw * 64;              // this wave's first output channel
+    const bool wave_live = co_wave < p.Cout;
     const int ty0 = (trem / p.tiles_x) * TH;
     const int tx0 = (trem % p.tiles_x) * TW;
     const int HW = p.H * p.W;
@@ -76,14 +101,17 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
         const int f = piece * 64 + lane;
         const int kg = f / PATCH;
         const int e = f - kg * PATCH;
-        const int hy = e / LW, hx = e - hy * LW;
+        const int ti = e / (LH * LW);
+        const int rr = e - ti * (LH * LW);
+        const int hy = rr / LW, hx = rr - hy * LW;
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        const bool ok = kg < 2 && n0 < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        x_off[u] = ok ? ((unsigned)((n0 * p.C8 + kg) * HW + gy * p.W + gx) << 4) : kOutOfRange;
+        const int n = n0 + ti;
+        const bool ok = kg < 2 && n < p.B && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        x_off[u] = ok ? ((unsigned)((n * p.C8 + kg) * HW + gy * p.W + gx) << 4) : kOutOfRange;
     }
     const size_t xplane_bytes = (size_t)p.B * p.C8 * HW * 16;
     auto dma_x = [&](int chunk, int buf, int q) __attribute__((always_inline)) {
-        const int u = q >> 1, plane = q & 1;
+        const int u = X1 ? q : q >> 1, plane = X1 ? 0 : q & 1;
         int piece = wave + u * 4;
         if (piece > NPIECE - 1) piece = NPIECE - 1;
         const size_t coff = (size_t)chunk * 2 * HW * 16;
@@ -91,65 +119,87 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
         BLDS6(rx, smem7 + buf * 2 * XB + plane * XB + piece * 1024, x_off[u], 0);
     };
 
-    // ---- B fragments: pixel tile j of this wave = tile row 4 pw + j; entry lane_b + (row + dy) * LW + dx
-    const int lane_b = l31 + half * PATCH + (4 * pw) * LW;
+    // ---- B fragments: this wave's pixel tiles are 4 pw .. 4 pw + 3 of conv6's eight (tile_off is additive in the wave part)
+    auto tile_off = [](int j) constexpr -> int { return GEO == 0 ? j * LW : (GEO == 1 ? 2 * j * LW : (j >> 1) * (LH * LW) + (j & 1) * 4 * LW); };
+    const int wave_off = NARROW ? 2 * pw * LW : (GEO == 0 ? 4 * pw * LW : (GEO == 1 ? 8 * pw * LW : 2 * pw * (LH * LW)));
+    const int lane_b = (GEO == 0 ? l31 : (GEO == 1 ? (l31 >> 4) * LW + (l31 & 15) : (l31 >> 3) * LW + (l31 & 7))) + half * PATCH + wave_off;
     const half8* xbase = reinterpret_cast<const half8*>(smem7) + lane_b;
 
     // ---- A fragments straight from the weight pack: record (chunk, co_blk, co-tile ct, tap) = 2 KiB [hi | lo], 16 B per lane
     const unsigned lane16 = (unsigned)lane * 16u;
-    half8 a_h[3][2], a_l[3][2];
+    half8 a_h[3][CT], a_l[3][CT];
     auto load_a = [&](int chunk, int tap, int slot) __attribute__((always_inline)) {
         const char* base = p.w16 + ((size_t)chunk * p.n_co_blocks + co_blk) * (4 * TAPS * 2048);
         const __amdgpu_buffer_rsrc_t rw = rsrc_uniform(base, 4 * TAPS * 2048);
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < CT; ++i) {
             const unsigned so = (unsigned)(((2 * cw + i) * TAPS + tap) * 2048);
             a_h[slot][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, so, 0));
-            a_l[slot][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, so + 1024u, 0));
+            if (!X1) a_l[slot][i] = __builtin_bit_cast(half8, __builtin_amdgcn_raw_buffer_load_b128(rw, lane16, so + 1024u, 0));
         }
     };
 
-    floatx16 acc[2][4];
+    floatx16 acc[CT][2 * TPG];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < CT; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 2 * TPG; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    half8 b_h[2][2], b_l[2][2];      // two pixel tiles per set, two sets (one in use, one being filled)
+    half8 b_h[2][TPG], b_l[2][TPG];  // TPG pixel tiles per set, two sets (one in use, one being filled)
     auto read_b = [&](int buf, int tap, int grp, int set) __attribute__((always_inline)) {      // pixel tiles 2 grp, 2 grp + 1
         const half8* xh = xbase + buf * (2 * XB / 16);
         const half8* xl = xh + XB / 16;
         const int toff = (tap / 3) * LW + (tap % 3);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int o = (grp * 2 + j) * LW + toff;
+        for (int j = 0; j < TPG; ++j) {
+            const int o = tile_off(grp * TPG + j) + toff;
             b_h[set][j] = xh[o];
-            b_l[set][j] = xl[o];
+            if (!X1) b_l[set][j] = xl[o];
         }
     };
     auto mfma_group = [&](int grp, int set, int slot) __attribute__((always_inline)) {
         // per accumulator: al * bh, ah * bl, ah * bh -- conv6's order
+        if (!X1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[slot][i], b_h[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+                for (int j = 0; j < TPG; ++j) acc[i][grp * TPG + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_l[slot][i], b_h[set][j], acc[i][grp * TPG + j], 0, 0, 0);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_l[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+                for (int j = 0; j < TPG; ++j) acc[i][grp * TPG + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_l[set][j], acc[i][grp * TPG + j], 0, 0, 0);
+        }
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < CT; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) acc[i][grp * 2 + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_h[set][j], acc[i][grp * 2 + j], 0, 0, 0);
+            for (int j = 0; j < TPG; ++j) acc[i][grp * TPG + j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a_h[slot][i], b_h[set][j], acc[i][grp * TPG + j], 0, 0, 0);
     };
+
+    // Waves whose 64 output channels lie beyond Cout only carry their share of the activation DMA and keep the barrier count
+    // (prologue, one per chunk boundary, epilogue): no weights, no MFMAs.
+    if (!wave_live) {
+#pragma unroll
+        for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+        wait_vmcnt<0>();
+        __syncthreads();
+        int it = 0;
+        for (int chunk = ch_begin; chunk + 1 < ch_end; ++chunk, ++it) {
+#pragma unroll
+            for (int q = 0; q < NACT; ++q) dma_x(chunk + 1, (it & 1) ^ 1, q);
+            wait_vmcnt<0>();
+            __syncthreads();
+        }
+        __syncthreads();
+        return;
+    }
 
     // ---- prologue: first patch, weights of taps 0 and 1
 #pragma unroll
-    for (int q = 0; q < NACT; ++q) dma_x(0, 0, q);
-    load_a(0, 0, 0);
-    load_a(0, 1, 1);
+    for (int q = 0; q < NACT; ++q) dma_x(ch_begin, 0, q);
+    load_a(ch_begin, 0, 0);
+    load_a(ch_begin, 1, 1);
     wait_vmcnt<0>();
     __syncthreads();
     read_b(0, 0, 0, 0);
@@ -175,7 +225,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
             if (tap + 1 < TAPS) {
                 read_b(cur, tap + 1, 0, 0);
             } else if (MORE) {
-                wait_vmcnt<8>();
+                wait_vmcnt<2 * CT * NPL>();        // the weights of taps 7 and 8 (the next chunk's 0 and 1) may still be in flight
                 barrier_lds_only();
                 read_b(cur ^ 1, 0, 0, 0);
             }
@@ -185,8 +235,8 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
         });
     };
     {
-        int it = 0, chunk = 0;
-        for (; chunk + 1 < p.n_chunks_total; ++chunk, ++it) chunk_body(std::true_type{}, chunk, it);
+        int it = 0, chunk = ch_begin;
+        for (; chunk + 1 < ch_end; ++chunk, ++it) chunk_body(std::true_type{}, chunk, it);
         chunk_body(std::false_type{}, chunk, it);
     }
 
@@ -194,15 +244,17 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
     // 32 co x 64 px: bias, un-scaling, residual in its three forms, GroupNorm partial sums (slot = the 64-pixel group of the tile)
     __syncthreads();
     constexpr int TS = 68;
-    constexpr int GPI = 4;                                   // 64-pixel groups per tile
+    constexpr int GPI = (TW * TH) / 64;                      // 64-pixel groups per image inside one tile
     float* tr = reinterpret_cast<float*>(smem7) + wave * (32 * TS);
     const int q4 = lane & 15, rsub = lane >> 4;
-    const float osc = p.out_scale;
-    const bool do_stat = p.stat != nullptr;
-    const int res_mode = p.res ? p.res_mode : -1;
+    const bool single = p.ksplit == 1;
+    const float osc = p.out_scale_dev ? p.out_scale * p.out_scale_dev[0] : p.out_scale;
+    const bool do_stat = p.stat != nullptr && single;
+    const int res_mode = (single && p.res) ? p.res_mode : -1;
+    float* const dst = single ? p.out : p.partial + (size_t)split * ((size_t)p.B * p.Cout * HW);
     const size_t img0 = (size_t)n0 * p.Cout;
     const size_t res_plane = res_mode == 1 ? (size_t)(HW >> 2) : (res_mode == 2 ? (size_t)HW * 4 : (size_t)HW);
-    float* const out_base = p.out + img0 * HW;
+    float* const out_base = dst + img0 * HW;
     const float* const res_base = res_mode >= 0 ? p.res + img0 * res_plane : p.bias;
     const unsigned res_bytes = res_mode >= 0 ? 0xFFFFFFFFu : 0u;
     const void* const stat_base = do_stat ? (const void*)(p.stat + img0 * p.stat_slots) : (const void*)p.bias;
@@ -210,23 +262,23 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
     typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     auto f4 = [](u32x4 v) { return make_float4(as_f32(v.x), as_f32(v.y), as_f32(v.z), as_f32(v.w)); };
-    const int co_wave = co_blk * 128 + cw * 64;              // this wave's first output channel
 
-    float bv[2][8];
+    float bv[CT][8];
     {
-        const __amdgpu_buffer_rsrc_t r_bias = rsrc_uniform(p.bias, (unsigned)p.Cout * 4u);
+        const __amdgpu_buffer_rsrc_t r_bias = rsrc_uniform(p.bias, single ? (unsigned)p.Cout * 4u : 0u);
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < CT; ++i)
 #pragma unroll
             for (int it = 0; it < 8; ++it) bv[i][it] = as_f32(__builtin_amdgcn_raw_buffer_load_b32(r_bias, (unsigned)(co_wave + i * 32 + it * 4 + rsub) * 4u, 0, 0));
     }
-    struct PassGeo { int y, x; bool pok; unsigned pix; };
+    struct PassGeo { int ti, y, x; bool pok; unsigned pix; };
     auto geo = [&](int q) {
-        const int pp = (pw * 2 + (q & 1)) * 64 + q4 * 4;
+        const int pp = (NARROW ? pw : pw * 2 + (q & 1)) * 64 + q4 * 4;
         PassGeo g;
-        g.y = ty0 + (pp >> 5);
-        g.x = tx0 + (pp & 31);
-        g.pok = n0 < p.B && g.y < p.H && g.x < p.W;
+        g.ti = pp >> (G::LTW + G::LTH);
+        g.y = ty0 + ((pp >> G::LTW) & (TH - 1));
+        g.x = tx0 + (pp & (TW - 1));
+        g.pok = n0 + g.ti < p.B && g.y < p.H && g.x < p.W;
         g.pix = (unsigned)(g.y * p.W + g.x);
         return g;
     };
@@ -238,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int co = co0 + it * 4 + rsub;
-                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)co * (unsigned)HW + g.pix) * 4u : kOutOfRange;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * (unsigned)HW + g.pix) * 4u : kOutOfRange;
                 rv[it] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, off, 0, 0));
             }
         } else if (res_mode == 1) {                        // residual at half resolution, nearest up-sampling (unet.py:107)
@@ -246,7 +298,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #pragma unroll
             for (int it = 0; it < 8; ++it) {
                 const int co = co0 + it * 4 + rsub;
-                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)co * HWr + (unsigned)(g.y >> 1) * Wr + (unsigned)(g.x >> 1)) * 4u : kOutOfRange;
+                const unsigned off = (g.pok && co < p.Cout) ? ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(g.y >> 1) * Wr + (unsigned)(g.x >> 1)) * 4u : kOutOfRange;
                 const u32x2 r2 = __builtin_amdgcn_raw_buffer_load_b64(r_res, off, 0, 0);
                 const float a = as_f32(r2.x), b = as_f32(r2.y);
                 rv[it] = make_float4(a, a, b, b);
@@ -260,7 +312,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
                 for (int i2 = 0; i2 < 2; ++i2) {
                     const int co = co0 + (h * 2 + i2) * 4 + rsub;
                     const bool ok = g.pok && co < p.Cout;
-                    const unsigned off = ((unsigned)co * HWr + (unsigned)(2 * g.y) * Wr + (unsigned)(2 * g.x)) * 4u;
+                    const unsigned off = ((unsigned)(g.ti * p.Cout + co) * HWr + (unsigned)(2 * g.y) * Wr + (unsigned)(2 * g.x)) * 4u;
                     a0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off : kOutOfRange, 0, 0));
                     a1[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + 16u : kOutOfRange, 0, 0));
                     b0[i2] = f4(__builtin_amdgcn_raw_buffer_load_b128(r_res, ok ? off + Wr * 4u : kOutOfRange, 0, 0));
@@ -277,7 +329,8 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 
     float4 rv[2][8];
     load_res(0, rv[0]);
-    static_for7<0, 4>([&](auto q_c) __attribute__((always_inline)) {
+    constexpr int NPASS = CT * TPG;                          // passes of 32 co x 64 px
+    static_for7<0, NPASS>([&](auto q_c) __attribute__((always_inline)) {
         constexpr int q = decltype(q_c)::value;
         constexpr int i = q >> 1, jp = q & 1;
         const PassGeo g = geo(q);
@@ -287,8 +340,8 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r)
                 tr[((r & 3) + 8 * (r >> 2) + 4 * half) * TS + jj * 32 + l31] = acc[i][jp * 2 + jj][r] * osc;
-        if (q + 1 < 4) load_res(q + 1, rv[(q + 1) & 1]);   // requested before this pass's stores
-        const int slot = trem * GPI + pw * 2 + jp;
+        if (q + 1 < NPASS) load_res(q + 1, rv[(q + 1) & 1]);   // requested before this pass's stores
+        const int slot = trem * GPI + ((NARROW ? pw : pw * 2 + jp) % GPI);
         const __amdgpu_buffer_rsrc_t r_out = rsrc_uniform(out_base, 0xFFFFFFFFu);
         const __amdgpu_buffer_rsrc_t r_stat = rsrc_uniform(stat_base, stat_bytes);
 #pragma unroll
@@ -305,7 +358,8 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
             if (!ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             u32x4 sv;
             sv.x = as_u32(v.x); sv.y = as_u32(v.y); sv.z = as_u32(v.z); sv.w = as_u32(v.w);
-            __builtin_amdgcn_raw_buffer_store_b128(sv, r_out, ok ? ((unsigned)co * (unsigned)HW + g.pix) * 4u : kOutOfRange, 0, 0);
+            const unsigned plane_l = (unsigned)(g.ti * p.Cout + co);
+            __builtin_amdgcn_raw_buffer_store_b128(sv, r_out, ok ? (plane_l * (unsigned)HW + g.pix) * 4u : kOutOfRange, 0, 0);
             if (do_stat) {
                 float s1 = (v.x + v.y) + (v.z + v.w);
                 float s2 = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
@@ -315,21 +369,41 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
                 s1 += dpp_row_shr7<0x118>(s1); s2 += dpp_row_shr7<0x118>(s2);
                 u32x2 st;
                 st.x = as_u32(s1); st.y = as_u32(s2);
-                const bool wr = q4 == 15 && co < p.Cout && n0 < p.B;
-                __builtin_amdgcn_raw_buffer_store_b64(st, r_stat, wr ? ((unsigned)co * (unsigned)p.stat_slots + (unsigned)slot) * 8u : kOutOfRange, 0, 0);
+                const bool wr = q4 == 15 && co < p.Cout && n0 + g.ti < p.B;
+                __builtin_amdgcn_raw_buffer_store_b64(st, r_stat, wr ? (plane_l * (unsigned)p.stat_slots + (unsigned)slot) * 8u : kOutOfRange, 0, 0);
             }
         }
     });
 #endif
 }
 
-Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks) {
-    if (k.ksplit != 1 || k.out_scale_dev || k.W < 32) return invalid("conv7: whole-K launches of the 8 x 32 geometry only");
-    constexpr size_t LDS = (size_t)4 * 11 * 1024;                  // two buffers x (hi, lo) x 11 KiB; the epilogue slabs (34 KiB) alias them
+template <int GEO, bool X1, bool NARROW = false>
+static Status launch7(hipStream_t s, const Conv6K& k, int blocks) {
+    using G = Geo7<GEO>;
+    constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
+    constexpr int NPIECE = (2 * PATCH + 63) / 64;
+    constexpr size_t LDS = (size_t)4 * NPIECE * 1024;           // two buffers x (hi, lo); the epilogue slabs (34 KiB) alias them
+    static_assert(LDS >= 4 * 32 * 68 * 4, "epilogue slabs");
+    auto fn = conv7_mfma_kernel<GEO, X1, NARROW>;
     static LdsAttrOnce attr_set;
-    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(conv7_mfma_kernel), (int)LDS));
-    hipLaunchKernelGGL(conv7_mfma_kernel, dim3((unsigned)blocks), dim3(256), LDS, s, k);
+    DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), (int)LDS));
+    hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), LDS, s, k);
     return Status{};
+}
+
+// k as launch_conv6 fills it (geometry from H, W as conv6_geo); blocks = pixel tiles x co-blocks x ksplit
+Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks, bool x1) {
+    if ((k.W & 3) || k.W < 8 || k.H < 8) return invalid("conv7: shape not tiled");
+    const int geo = k.W >= 32 ? 0 : (k.W >= 16 ? 1 : 2);
+    if (geo == 0 && k.Cout <= 32) return x1 ? launch7<0, true, true>(s, k, blocks) : launch7<0, false, true>(s, k, blocks);
+    if (x1) {
+        if (geo == 0) return launch7<0, true>(s, k, blocks);
+        if (geo == 1) return launch7<1, true>(s, k, blocks);
+        return launch7<2, true>(s, k, blocks);
+    }
+    if (geo == 0) return launch7<0, false>(s, k, blocks);
+    if (geo == 1) return launch7<1, false>(s, k, blocks);
+    return launch7<2, false>(s, k, blocks);
 }
 
 }  // namespace dpir

@@ -5,7 +5,6 @@
 #include "../../include/diffpir_debug.h"
 #include <vector>
 using namespace dpir;
-namespace dpir { Status launch_conv7x(hipStream_t s, const Conv6K& k, int blocks, bool x1); }
 static int fail(dpir_engine* e, const Status& s) {
     if (e) e->last_error = s.msg;
     return s.code;
@@ -109,90 +108,14 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
     return DPIR_OK;
 }
 
-// conv7 against conv6 on the same split planes and weight pack (include/diffpir_debug.h): outputs and fused GroupNorm sums must
-// agree bit for bit; then both kernels are timed back to back.  res_mode: -1 none, 0 same shape, 1 half resolution, 2 double resolution.
-int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int iters,
-                           double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out) {
-    if (!e || !ms6_out || !ms7_out || !mismatches_out || !maxdiff_out || iters <= 0 || res_mode < -1 || res_mode > 2) return DPIR_ERR_INVALID;
-    (void)hipSetDevice(e->device);
-    const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W;
-    const size_t nres = res_mode == 1 ? no / 4 : (res_mode == 2 ? no * 4 : no);
-    const int slots = conv6_stat_slots(H, W);
-    const size_t nst = (size_t)B * Cout * slots;
-    float *x = nullptr, *bias = nullptr, *o6 = nullptr, *o7 = nullptr, *res = nullptr;
-    float2 *st6 = nullptr, *st7 = nullptr;
-    unsigned long long* cmp = nullptr;
-    API_TRY(e, e->ws.getT("c7#x", nx, &x));
-    API_TRY(e, e->ws.getT("c7#b", (size_t)round_up(Cout, 64), &bias));
-    API_TRY(e, e->ws.getT("c7#o6", no, &o6));
-    API_TRY(e, e->ws.getT("c7#o7", no, &o7));
-    API_TRY(e, e->ws.getT("c7#res", nres, &res));
-    API_TRY(e, e->ws.getT("c7#st6", nst, &st6));
-    API_TRY(e, e->ws.getT("c7#st7", nst, &st7));
-    API_TRY(e, e->ws.getT("c7#cmp", (size_t)2, &cmp));
-    API_TRY(e, launch_randn(e->stream, x, 11, 1, 0, 1, nx));
-    API_TRY(e, launch_randn(e->stream, bias, 12, 1, 0, 1, (size_t)round_up(Cout, 64)));
-    API_TRY(e, launch_randn(e->stream, res, 13, 1, 0, 1, nres));
-    std::vector<float> hw((size_t)Cout * Cin * 9);
-    for (size_t i = 0; i < hw.size(); ++i) hw[i] = (float)((i * 2654435761u) % 2001) / 1000.0f * 0.05f - 0.05f;
-    std::vector<uint16_t> w16v;
-    const float w16_scale = pack_weights_conv6(hw.data(), Cout, Cin, w16v);
-    void* wp = nullptr;
-    API_TRY(e, e->ws.get("c7#w16", w16v.size() * 2, &wp));
-    API_HIP(e, hipMemcpy(wp, w16v.data(), w16v.size() * 2, hipMemcpyHostToDevice));
-    const int C8 = 2 * ((Cin + 15) / 16);
-    const size_t plane = (size_t)B * C8 * H * W * 16;
-    char* s16 = nullptr;
-    API_TRY(e, e->ws.getT("c7#s16", 2 * plane, &s16));
-    API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, nullptr, 0, B, H, W, s16, s16 + plane));
-    Conv6Args a6;
-    a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = wp; a6.w16_scale = w16_scale; a6.bias = bias;
-    a6.B = B; a6.Cin = Cin; a6.Cout = Cout; a6.H = H; a6.W = W;
-    if (res_mode >= 0) { a6.res = res; a6.res_mode = res_mode; }
-    Conv6Args a7 = a6;
-    a6.out = o6; a6.stat = st6; a6.force_kernel = 6;
-    a7.out = o7; a7.stat = st7; a7.force_kernel = 7;
-    API_HIP(e, hipMemsetAsync(o6, 0xFF, no * 4, e->stream));
-    API_HIP(e, hipMemsetAsync(o7, 0x7F, no * 4, e->stream));
-    API_HIP(e, hipMemsetAsync(st6, 0xFF, nst * 8, e->stream));
-    API_HIP(e, hipMemsetAsync(st7, 0x7F, nst * 8, e->stream));
-    API_HIP(e, hipMemsetAsync(cmp, 0, 16, e->stream));
-    int k6 = 0, k7 = 0;
-    API_TRY(e, launch_conv6(e->stream, a6, &k6));
-    API_TRY(e, launch_conv6(e->stream, a7, &k7));
-    if (k6 != 1 || k7 != 1) return fail(e, Status{DPIR_ERR_INVALID, "conv7 check: the shape does not take the fused-statistics whole-K route"});
-    hipLaunchKernelGGL(dbg_bitdiff_kernel, dim3(2048), dim3(256), 0, e->stream, o6, o7, no, cmp);
-    hipLaunchKernelGGL(dbg_bitdiff_kernel, dim3(256), dim3(256), 0, e->stream, reinterpret_cast<const float*>(st6), reinterpret_cast<const float*>(st7), nst * 2, cmp);
-    unsigned long long h[2] = {0, 0};
-    API_HIP(e, hipMemcpyAsync(h, cmp, 16, hipMemcpyDeviceToHost, e->stream));
-    API_HIP(e, hipStreamSynchronize(e->stream));
-    *mismatches_out = h[0];
-    const unsigned mb = (unsigned)h[1];
-    *maxdiff_out = __builtin_bit_cast(float, mb);
-    hipEvent_t e0, e1, e2;
-    API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1)); API_HIP(e, hipEventCreate(&e2));
-    for (int i = 0; i < 3; ++i) { API_TRY(e, launch_conv6(e->stream, a6)); API_TRY(e, launch_conv6(e->stream, a7)); }
-    API_HIP(e, hipEventRecord(e0, e->stream));
-    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv6(e->stream, a6));
-    API_HIP(e, hipEventRecord(e1, e->stream));
-    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv6(e->stream, a7));
-    API_HIP(e, hipEventRecord(e2, e->stream));
-    API_HIP(e, hipEventSynchronize(e2));
-    float m6 = 0, m7 = 0;
-    API_HIP(e, hipEventElapsedTime(&m6, e0, e1)); API_HIP(e, hipEventElapsedTime(&m7, e1, e2));
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1); (void)hipEventDestroy(e2);
-    *ms6_out = m6 / iters; *ms7_out = m7 / iters;
-    return DPIR_OK;
-}
-
-// conv7x (csrc/conv7x.hip, the generalisation of conv7 to every conv6 case) against conv6: outputs + statistics (whole K) or the
-// split-K partial slabs must agree bit for bit.  x1: f16x1 planes / products; split: give both kernels a partial buffer so that the
+// conv7 (csrc/conv7.hip) against conv6 (8 x 32 geometry: the only one conv6 is still built for) on the same split planes and weight
+// pack: outputs + fused GroupNorm statistics (whole K) or the split-K partial slabs must agree bit for bit; then both are timed back to back.  x1: f16x1 planes / products; split: give both kernels a partial buffer so that the
 // launch is split along K when launch_conv6's rule says so; scaled: a device output scale of 0.25 (the dgrad route).
-int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
+int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
                             double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out, int* ksplit_out) {
     if (!e || !ms6_out || !ms7_out || !mismatches_out || !maxdiff_out || !ksplit_out || iters <= 0 || res_mode < -1 || res_mode > 2) return DPIR_ERR_INVALID;
     (void)hipSetDevice(e->device);
-    if (!conv6_supported(H, W)) return fail(e, invalid("conv7x check: shape not tiled"));
+    if (!conv6_supported(H, W) || W < 32) return fail(e, invalid("conv7 check: conv6 only has the 8 x 32 geometry (W >= 32) to compare with"));
     const size_t nx = (size_t)B * Cin * H * W, no = (size_t)B * Cout * H * W;
     const size_t nres = res_mode == 1 ? no / 4 : (res_mode == 2 ? no * 4 : no);
     const int slots = conv6_stat_slots(H, W);
@@ -235,7 +158,7 @@ int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int
     if (scaled) a6.out_scale_dev = scale;
     a6.out = o6; a6.stat = st6; a6.force_kernel = 6;
     if (split) { a6.partial = p6; a6.partial_capacity = pcap; }
-    // the parameter block launch_conv6 would build, for conv7x (same tiling and the same split rule)
+    // the parameter block launch_conv6 would build, for conv7 (same tiling and the same split rule)
     Conv6K k;
     k.xhi = reinterpret_cast<const char*>(a6.xhi); k.xlo = reinterpret_cast<const char*>(a6.xlo);
     k.w16 = reinterpret_cast<const char*>(wp); k.bias = bias; k.out = o7; k.res = a6.res; k.res_mode = a6.res_mode;
@@ -269,8 +192,8 @@ int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int
     int k6 = 0;
     PendingConv pend;
     API_TRY(e, launch_conv6(e->stream, a6, &k6, &pend));
-    if ((S > 1) != (k6 == 3) || (S > 1 && pend.ksplit != S)) return fail(e, Status{DPIR_ERR_INVALID, "conv7x check: the split rule of launch_conv6 changed"});
-    API_TRY(e, launch_conv7x(e->stream, k, blocks * S, x1 != 0));
+    if ((S > 1) != (k6 == 3) || (S > 1 && pend.ksplit != S)) return fail(e, Status{DPIR_ERR_INVALID, "conv7 check: the split rule of launch_conv6 changed"});
+    API_TRY(e, launch_conv7(e->stream, k, blocks * S, x1 != 0));
     API_HIP(e, hipGetLastError());
     if (S > 1) {
         hipLaunchKernelGGL(dbg_bitdiff_kernel, dim3(2048), dim3(256), 0, e->stream, p6, p7, (size_t)S * no, cmp);
@@ -286,11 +209,11 @@ int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int
     *maxdiff_out = __builtin_bit_cast(float, mb);
     hipEvent_t e0, e1, e2;
     API_HIP(e, hipEventCreate(&e0)); API_HIP(e, hipEventCreate(&e1)); API_HIP(e, hipEventCreate(&e2));
-    for (int i = 0; i < 3; ++i) { API_TRY(e, launch_conv6(e->stream, a6, &k6, &pend)); API_TRY(e, launch_conv7x(e->stream, k, blocks * S, x1 != 0)); }
+    for (int i = 0; i < 3; ++i) { API_TRY(e, launch_conv6(e->stream, a6, &k6, &pend)); API_TRY(e, launch_conv7(e->stream, k, blocks * S, x1 != 0)); }
     API_HIP(e, hipEventRecord(e0, e->stream));
     for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv6(e->stream, a6, &k6, &pend));
     API_HIP(e, hipEventRecord(e1, e->stream));
-    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv7x(e->stream, k, blocks * S, x1 != 0));
+    for (int i = 0; i < iters; ++i) API_TRY(e, launch_conv7(e->stream, k, blocks * S, x1 != 0));
     API_HIP(e, hipEventRecord(e2, e->stream));
     API_HIP(e, hipEventSynchronize(e2));
     float m6 = 0, m7 = 0;

@@ -77,7 +77,12 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
     // __syncthreads) -- 19 -> 10.7 KiB per workgroup at N = 256, 8 -> 14 resident workgroups per CU (pays at B >= 64)
     float2* zbuf = xch;
     if (sp) pm = sp->tau;
-    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
+    // the twiddle table is requested FIRST but stored to LDS only after the row loads below are in flight too: a load -> ds_write pair
+    // in front of them would be a whole memory round trip before the first row request leaves the CU
+    constexpr int NTW = (N + THREADS - 1) / THREADS;
+    float2 twr[NTW];
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; twr[j] = i < N ? tw[i] : make_float2(0.f, 0.f); }
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
     const size_t ra = 2 * pair, rb = 2 * pair + 1;
@@ -105,6 +110,8 @@ __global__ __launch_bounds__(THREADS) void rfft_rows_kernel(const float* x, floa
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; if (i < N) twN[i] = twr[j]; }
 #pragma unroll
         for (int j = 0; j < NL; ++j) {
             const int i = threadIdx.x + j * THREADS;
@@ -168,7 +175,10 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
     float2* twN = sm2;
     float2* xch = sm2 + N;
     float2* zbuf = xch;                                 // aliased with the exchange area (see rfft_rows_kernel)
-    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
+    constexpr int NTW = (N + THREADS - 1) / THREADS;
+    float2 twr[NTW];                                    // requested first, stored after the spectrum loads are in flight (see rfft_rows_kernel)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; twr[j] = i < N ? tw[i] : make_float2(0.f, 0.f); }
     const int slot = threadIdx.x / R, t = threadIdx.x % R;
     const size_t pair = (size_t)blockIdx.x * SLOTS + slot;
     const size_t ra = 2 * pair, rb = 2 * pair + 1;
@@ -187,6 +197,22 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
             if (vb) Bw[j] = in[rb * WP + ks];
         }
     }
+    // what the epilogue combines with the transform's result (x_t for the fused re-noise, or the guidance-blend base) does not depend on
+    // it: requested here, so that its latency hides under the transform instead of following it
+    const size_t row0 = (size_t)blockIdx.x * SLOTS * 2;
+    constexpr int V4 = N / 4;
+    constexpr int NS4 = (2 * SLOTS * V4 + THREADS - 1) / THREADS;
+    const float* pre_src = rn.xt ? rn.xt : blend_base;
+    float4 pre[NS4];
+#pragma unroll
+    for (int j = 0; j < NS4; ++j) {
+        const int i = threadIdx.x + j * THREADS;
+        const int r = i / V4, c4 = i - r * V4;
+        pre[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (pre_src && i < 2 * SLOTS * V4 && row0 + r < total_rows) pre[j] = *reinterpret_cast<const float4*>(pre_src + (row0 + r) * N + c4 * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; if (i < N) twN[i] = twr[j]; }
 #pragma unroll
     for (int j = 0; j < NK; ++j) {
         const int k = t + j * R;
@@ -211,16 +237,17 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
         stage[(2 * slot + 1) * (N + 4) + n] = (v[k2].y * scale) * oa + ob;
     }
     __syncthreads();
-    const size_t row0 = (size_t)blockIdx.x * SLOTS * 2;
-    constexpr int V4 = N / 4;
-    for (int i = threadIdx.x; i < 2 * SLOTS * V4; i += THREADS) {
+#pragma unroll
+    for (int j = 0; j < NS4; ++j) {
+        const int i = threadIdx.x + j * THREADS;
+        if (i >= 2 * SLOTS * V4) continue;
         int r = i / V4, c4 = i - r * V4;
         size_t row = row0 + r;
         if (row >= total_rows) continue;
         float4 q = *reinterpret_cast<const float4*>(stage + r * (N + 4) + c4 * 4);
         size_t gi = row * N + c4 * 4;
         if (blend_base) {
-            float4 b0 = *reinterpret_cast<const float4*>(blend_base + gi);
+            float4 b0 = rn.xt ? *reinterpret_cast<const float4*>(blend_base + gi) : pre[j];
             q.x = b0.x + g * (q.x - b0.x); q.y = b0.y + g * (q.y - b0.y); q.z = b0.z + g * (q.z - b0.z); q.w = b0.w + g * (q.w - b0.w);
         }
         if (rn.xt) {
@@ -241,7 +268,7 @@ __global__ __launch_bounds__(THREADS) void irfft_rows_kernel(const float2* in, f
                 philox_normal4(rn.lp->seed, 2 + 4 * (uint64_t)st.i, img, e >> 2, z2);
                 if (rn.with_n1) philox_normal4(rn.lp->seed, 1 + 4 * (uint64_t)st.i, img, e >> 2, z1);
             }
-            const float4 xo = *reinterpret_cast<const float4*>(rn.xt + gi);
+            const float4 xo = pre[j];
             const float xv[4] = {xo.x, xo.y, xo.z, xo.w}, av[4] = {q.x, q.y, q.z, q.w};
             float rv[4];
 #pragma unroll
@@ -271,7 +298,10 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
     float2* twN = sm2;
     float2* xch = sm2 + N;                              // [CS][RJ*(R+1)+1]  (+1: lanes of a wave walk the slots)
     constexpr int XST = RJ * (R + 1) + 1;
-    for (int i = threadIdx.x; i < N; i += THREADS) twN[i] = tw[i];
+    constexpr int NTW = (N + THREADS - 1) / THREADS;
+    float2 twr[NTW];                                    // requested first, stored once the column loads are in flight (see rfft_rows_kernel)
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; twr[j] = i < N ? tw[i] : make_float2(0.f, 0.f); }
     const int c = threadIdx.x % CS, t = threadIdx.x / CS;     // lanes walk the strip's columns: 128-byte row segments
     const int strips = WP / CS;
     const int plane = blockIdx.x / strips;
@@ -280,6 +310,23 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
     float2 v[RJ];
 #pragma unroll
     for (int n1 = 0; n1 < RJ; ++n1) v[n1] = base[(size_t)(R * n1 + t) * WP];
+    // sf = 1 solve: its three spectra do not depend on the transform -- requested together with the data (one memory round trip instead of
+    // a second one between the forward and the inverse transform); RJ <= 16 keeps this at 5 * RJ extra registers
+    constexpr bool PRE = MODE == 2 && RJ <= 16;
+    float2 pFB[PRE ? RJ : 1], pFy[PRE ? RJ : 1]; float pF2[PRE ? RJ : 1];
+    if (PRE) {
+        const int n_img = plane / 3;
+        const float2* FB = a.FB + (size_t)n_img * N * WP + col;
+        const float* F2B = a.F2B + (size_t)n_img * N * WP + col;
+        const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
+#pragma unroll
+        for (int k2 = 0; k2 < (PRE ? RJ : 1); ++k2) {
+            const size_t off = (size_t)(t + R * k2) * WP;
+            pFB[k2] = FB[off]; pFy[k2] = FBFy[off]; pF2[k2] = F2B[off];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; if (i < N) twN[i] = twr[j]; }
     __syncthreads();
     fft_two_pass<R, RJ, false>(v, t, xch + c * XST, twN);
     if (MODE == 2) {
@@ -291,10 +338,10 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
 #pragma unroll
         for (int k2 = 0; k2 < RJ; ++k2) {
             size_t off = (size_t)(t + R * k2) * WP;
-            float2 fr = cadd(FBFy[off], v[k2]);
-            float2 fb = FB[off];
+            float2 fr = cadd(PRE ? pFy[k2] : FBFy[off], v[k2]);
+            float2 fb = PRE ? pFB[k2] : FB[off];
             float2 x1 = cmul2(fb, fr);
-            float den = F2B[off] + alpha;
+            float den = (PRE ? pF2[k2] : F2B[off]) + alpha;
             float2 q = make_float2(x1.x / den, x1.y / den);
             float2 tq = cmulc2(q, fb);                          // conj(FB) * q
             v[k2] = make_float2((fr.x - tq.x) / alpha, (fr.y - tq.y) / alpha);

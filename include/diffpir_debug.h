@@ -20,16 +20,14 @@ int dpir_debug_victim_alu(dpir_engine* e, int mode, int blocks, int iters_in_ker
  * threads whose two identical computations disagreed. */
 int dpir_debug_victim_fft_pk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
 int dpir_debug_victim_fft_nopk(dpir_engine* e, int blocks, int iters_in_kernel, int launches, unsigned long long* bad_out);
-/* conv7 (csrc/conv7.hip: 64 co x 128 px per wave, weights straight into registers) against conv6 on the same split planes and weight
- * pack, with fused GroupNorm sums and the residual form res_mode (-1 none, 0 same shape, 1 half resolution, 2 double resolution):
- * *mismatches_out = output + statistics elements whose bits differ (expected 0: same MFMA order per accumulator), *maxdiff_out their
- * largest absolute difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
-int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int iters,
-                           double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out);
-/* conv7x (csrc/conv7x.hip, test-only: conv7 generalised to every conv6 case) against conv6; x1: f16x1; split: allow split-K (the
- * partial slabs are compared instead of output + statistics; *ksplit_out = slabs); scaled: device output scale (dgrad route). */
-int dpir_debug_conv7x_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
-                            double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out, int* ksplit_out);
+/* conv7 (csrc/conv7.hip: 64 co x 128 px per wave, weights straight into registers; every launch class) against conv6 (csrc/conv6.hip,
+ * still built for the 8 x 32 geometry, W >= 32) on the same split planes and weight pack, with the residual form res_mode (-1 none,
+ * 0 same shape, 1 half resolution, 2 double resolution).  x1: f16x1 planes / products; split: allow split-K (the partial slabs are
+ * compared instead of output + fused GroupNorm statistics; *ksplit_out = slabs); scaled: a device output scale (the dgrad route).
+ * *mismatches_out = elements whose bits differ (expected 0: same MFMA order per accumulator), *maxdiff_out their largest absolute
+ * difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
+int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
+                           double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out, int* ksplit_out);
 #ifdef __cplusplus
 }
 #endif

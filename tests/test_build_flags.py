@@ -83,9 +83,12 @@ def test_hot_kernels_carry_no_compiler_inserted_serialisation():
             assert r["scratch"] == 0 and r["vmcnt0_before_ds_read"] <= 1 and r["vmcnt0_after_load"] <= 1, (sym, r)
         elif "conv7_mfma_kernel" in sym:
             seen["conv7_mfma_kernel"] += 1
-            # weights go straight into registers: only the activation patch is DMA'd (6 pieces in the prologue + 6 in the loop body)
-            assert r["scratch"] == 0 and r["vmcnt0_before_ds_read"] == 0 and r["vmcnt0_after_load"] == 0 and r["lds_dma"] == 12, (sym, r)
+            # weights go straight into registers: only the activation patch is DMA'd (per wave 2-3 pieces per plane in the prologue, as many
+            # in the loop body; the idle-co-half path repeats both)
+            assert r["scratch"] == 0 and r["vmcnt0_before_ds_read"] == 0 and r["vmcnt0_after_load"] <= 1 and 4 <= r["lds_dma"] <= 32, (sym, r)        # <= 1: the scalar read of the run-time output scale
         elif "attention_kernel" in sym:
             seen["attention_kernel"] += 1
             assert r["vmcnt0_after_load"] == 0 and r["scratch"] == 0, (sym, r)
-    assert seen == {"conv5_mfma_kernel": 6, "conv6_mfma_kernel": 6, "conv7_mfma_kernel": 1, "attention_kernel": 1}, seen
+    # conv7: (3 geometries + the narrow variant of the 8 x 32 one) x {f16x3, f16x1}; conv6: the 8 x 32 geometry x {f16x3, f16x1}
+    # (split-K and idle-co-half launches)
+    assert seen == {"conv5_mfma_kernel": 6, "conv6_mfma_kernel": 2, "conv7_mfma_kernel": 8, "attention_kernel": 1}, seen

@@ -173,14 +173,18 @@ def test_device_randn_statistics_and_shard_invariance(engine):
 
 
 def test_conv7_is_bit_identical_to_conv6(engine):
-    """csrc/conv7.hip (64 co x 128 px per wave, weights straight into registers) takes over conv6's geometry-0 whole-K launches on the
-    strength of producing the SAME bits: outputs and fused GroupNorm sums, for every residual form (tools/conv7_check.py, through the
-    test-only library).  Three small cases here; the tool's default list covers the benched layer shapes."""
+    """csrc/conv7.hip (64 co x 128 px per wave, weights straight into registers) is the 3x3 kernel of the f16 modes on the strength of
+    producing the SAME bits as conv6: outputs and fused GroupNorm sums for every residual form, split-K slabs, f16x1, the dgrad scale,
+    idle / partially filled co-halves (tools/conv7_check.py, through the test-only library; conv6 is still built for the 8 x 32
+    geometry, which is where the two can be compared -- all three geometries were compared in profiles/r04/conv7x_check.log)."""
     import importlib.util
     import os
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     spec = importlib.util.spec_from_file_location("conv7_check", os.path.join(root, "tools", "conv7_check.py"))
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
-    cases = [(2, 128, 128, 64, 64, (-1, 0, 1, 2)), (3, 48, 128, 40, 72, (0, 2)), (1, 6, 128, 96, 96, (-1,))]
+    # (B, Cin, Cout, H, W, res_mode, x1, split, scaled)
+    cases = [(2, 128, 128, 64, 64, m, 0, 0, 0) for m in (-1, 0, 1, 2)] + [(3, 48, 128, 40, 72, 0, 0, 0, 0), (3, 48, 128, 40, 72, 2, 1, 0, 0),
+             (1, 6, 128, 96, 96, -1, 0, 0, 0), (2, 512, 256, 32, 32, 0, 0, 1, 0), (2, 64, 6, 64, 64, -1, 0, 0, 0), (2, 64, 200, 32, 32, 1, 0, 0, 1),
+             (2, 64, 3, 64, 64, -1, 0, 0, 1), (3, 48, 24, 40, 72, 0, 1, 0, 0), (2, 512, 32, 32, 32, 1, 0, 1, 0)]
     assert mod.run(iters=1, cases=cases, engine=engine) == 0

@@ -1,7 +1,8 @@
 #!/bin/bash
-# Round-3 rocprofv3 passes (kernel trace and one PMC pass per counter group, never combined with other trace domains) over
+# The round's rocprofv3 passes (kernel trace and one PMC pass per counter group, never combined with other trace domains) over
 # tools/prof_forward.py for: FFHQ f16x3 B=16 (headline), ImageNet-256 f16x3 B=32 + sf=4 prox (config 3), FFHQ f32, FFHQ f16x1.
-# usage: tools/gpu_prof_r3.sh <tag>   -> gpurun_out/<tag>/<case>_<pass>.txt
+# usage: tools/gpu_prof_round.sh <tag> [headline]   -> gpurun_out/<tag>/<case>_<pass>.txt   ("headline": only the FFHQ f16x3 passes)
+# Copy the summaries into profiles/rNN/ and run `python tools/pmc_traffic.py profiles/rNN` to refresh profiles/pmc_traffic.json.
 tag=$1; out=$PWD/gpurun_out/$tag; mkdir -p $out
 export TMPDIR=/tmp
 run() { # case, pass, rocprof args...
@@ -17,6 +18,8 @@ run ffhq_f16x3 kernel_trace --kernel-trace
 run ffhq_f16x3 pmc_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 run ffhq_f16x3 pmc_FETCH_SIZE --kernel-trace --pmc FETCH_SIZE
 run ffhq_f16x3 pmc_WRITE_SIZE --kernel-trace --pmc WRITE_SIZE
+cp $GRAFT_REPO_ROOT/.commit_id $out/commit.txt 2>/dev/null || true
+[ "$2" = "headline" ] && exit 0
 export DIFFPIR_PRECISION=f32
 run ffhq_f32 kernel_trace --kernel-trace
 run ffhq_f32 pmc_FETCH_SIZE --kernel-trace --pmc FETCH_SIZE

@@ -1,4 +1,4 @@
-"""Fold the rocprofv3 PMC passes of tools/gpu_prof_r3.sh (FETCH_SIZE / WRITE_SIZE summaries written by tools/rocpd_summary.py) into
+"""Fold the rocprofv3 PMC passes of tools/gpu_prof_round.sh (FETCH_SIZE / WRITE_SIZE summaries written by tools/rocpd_summary.py) into
 profiles/pmc_traffic.json: HBM-side bytes per launch of the roofline kernel classes.  FETCH_SIZE is doubled as the gfx950 note of
 MI355X_MICROARCH.md prescribes for wide coalesced reads (counter unit KB); WRITE_SIZE as reported.
 usage: python tools/pmc_traffic.py <profiles dir> """
@@ -33,11 +33,11 @@ def klass(d, tag, pat, src):
     return {"bytes_per_launch": round(tot_b / max(tot_n, 1)), "dispatches": tot_n, "kernels": rows, "source": src}
 
 d = sys.argv[1]
-src = f"{d}/<case>_pmc_{{FETCH,WRITE}}_SIZE.txt: separate rocprofv3 --pmc passes over tools/prof_forward.py (tools/gpu_prof_r3.sh), FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, KB -> bytes, launch-weighted over the kernels of the class"
+src = f"{d}/<case>_pmc_{{FETCH,WRITE}}_SIZE.txt: separate rocprofv3 --pmc passes over tools/prof_forward.py (tools/gpu_prof_round.sh), FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, KB -> bytes, launch-weighted over the kernels of the class"
 out = {
-    "ffhq_B16_256_f16x3": klass(d, "ffhq_f16x3", r"conv6_mfma_kernel", src),
+    "ffhq_B16_256_f16x3": klass(d, "ffhq_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel", src),
     "ffhq_B16_256_f32": klass(d, "ffhq_f32", r"conv2_mfma_kernel<3|conv2_mfma_kernel<1, 8|conv_mfma_kernel<3", src),
-    "imagenet256_B32_256_f16x3": klass(d, "in256_f16x3", r"conv6_mfma_kernel", src),
+    "imagenet256_B32_256_f16x3": klass(d, "in256_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel", src),
     "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
     "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
 }
