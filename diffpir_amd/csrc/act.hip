@@ -174,6 +174,7 @@ struct GnActK {
     int mode, Hs, Ws, Ho, Wo, C8;
     _Float16* hi; _Float16* lo;
     unsigned long long* range_ctr;
+    float4* prm_out; float2* stats_out;        // optional (gradient mode): gn_prm_kernel's tables, for the backward pass
 };
 
 template <int CQ>
@@ -273,6 +274,8 @@ __global__ __launch_bounds__(1024) void gn_act_small_kernel(GnActK p) {
         }
         sh_a[tid] = a; sh_b[tid] = b;
         if (tid == 0) sh_mean = (float)mean;
+        if (p.prm_out) p.prm_out[(size_t)n * C + c] = make_float4((float)mean, a, b, p.act);
+        if (p.stats_out && tid == 0) p.stats_out[blockIdx.x] = make_float2((float)mean, rstd);
     }
     __syncthreads();
     // ---- pass 2
@@ -341,6 +344,7 @@ Status launch_gn_act_small(hipStream_t s, const GnActArgs& a) {
     k.C8 = 2 * ((C + 15) / 16);
     k.hi = reinterpret_cast<_Float16*>(a.hi); k.lo = reinterpret_cast<_Float16*>(a.lo);
     k.range_ctr = a.range_ctr;
+    k.prm_out = a.prm_out; k.stats_out = a.stats_out;
     const int cg = C / 32;
     const dim3 grid((unsigned)(a.B * 32));
     if (k.partial && (k.ksplit < 2 || k.ksplit > 16)) return invalid("gn_act_small: split-K factor out of range");

@@ -151,6 +151,8 @@ struct GnActArgs {
     const float* film = nullptr; int film_stride = 0; int film_off = 0; const StepDev* fstep = nullptr; int frows = 0;
     bool silu = true; int mode = 0; int B = 0, Hs = 0, Ws = 0;
     void* hi = nullptr; void* lo = nullptr; unsigned long long* range_ctr = nullptr;
+    // gradient mode: what the backward pass reads -- per-(image, channel) {mean, a, b, act} and per-(image, group) {mean, rstd}
+    float4* prm_out = nullptr; float2* stats_out = nullptr;
 };
 bool gn_act_small_supported(int C, int Hs, int Ws, int mode);
 Status launch_gn_act_small(hipStream_t s, const GnActArgs& a);
@@ -166,7 +168,10 @@ struct Conv6Args {
     bool x1 = false;               // single-product mode (f16x1): hi planes / hi weight halves only
     const float* out_scale_dev = nullptr;      // optional device scalar folded into the output scale (dgrad, unet_bwd.hip)
     int force_kernel = 0;          // tests only: 6 = conv6 even where conv7 applies, 7 = conv7 or an error; 0 = launch_conv6 decides
+    const struct Conv6Emit* emit = nullptr;    // conv6_params.h: fused emission of the NEXT convolution's operand planes instead of `out`
 };
+// true when a launch with these arguments runs whole-K on the 8 x 32 geometry with every tile inside the image (what Conv6Emit needs)
+bool conv7_emit_supported(int B, int Cout, int H, int W);
 bool conv6_supported(int H, int W);
 int conv6_stat_slots(int H, int W);
 // pend_out != null: a split-K launch leaves its slabs uncombined and describes them in *pend_out (stat kind 3); the caller must

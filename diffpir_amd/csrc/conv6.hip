@@ -519,6 +519,13 @@ static int conv6_geo(int H, int W) {
     return W >= 32 ? 0 : (W >= 16 ? 1 : 2);
 }
 bool conv6_supported(int H, int W) { return conv6_geo(H, W) >= 0; }
+// Conv6Emit: whole K (>= 384 workgroups, launch_conv6's rule), 8 x 32 tiles inside the image, full 128-channel blocks, and at most 256
+// workgroups per image so that an image's workgroups are resident together (two images fill the chip's 512 slots)
+bool conv7_emit_supported(int B, int Cout, int H, int W) {
+    if (conv6_geo(H, W) != 0 || (W & 31) || (H & 7) || (Cout & 127)) return false;
+    const int per_img = (W / 32) * (H / 8) * (Cout / 128);
+    return per_img <= 256 && per_img * B >= 384;
+}
 
 // statistics slots per (image, channel) plane written by the epilogue when no split-K is used
 int conv6_stat_slots(int H, int W) {
@@ -588,6 +595,13 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, Pendi
     k.ksplit = S;
     if (S == 1) k.partial = nullptr;
     k.stat = nullptr; k.stat_slots = 0;
+    if (a.emit) {
+        if (S != 1 || !conv7_emit_supported(a.B, a.Cout, a.H, a.W) || a.res || a.out_scale_dev) return invalid("conv6: this launch cannot emit the next convolution's planes");
+        k.em = *a.emit;
+        DPIR_TRY(launch_conv7(s, k, blocks, a.x1));
+        DPIR_HIP(hipGetLastError());
+        return Status{};
+    }
     if (a.stat && S == 1) {
         k.stat = a.stat; k.stat_slots = conv6_stat_slots(a.H, a.W);
         if (stat_kind_out) *stat_kind_out = 1;

@@ -3,6 +3,19 @@
 #include "common.h"
 namespace dpir {
 
+// Fused hop conv1 -> GroupNorm + FiLM + SiLU -> conv2 inside a ResBlock (round 4, conv7 only): conv1's epilogue does not store its fp32
+// output; it adds its per-group sums to per-image accumulators (fixed point: integer addition is associative, so the result does not
+// depend on the arrival order -- replays stay bitwise reproducible), waits until every workgroup of its image has arrived, folds the
+// GroupNorm parameters for its own 128 channels and writes conv2's operand planes (normalised, activated, split into f16 hi / lo) itself.
+struct Conv6Emit {
+    char* hi = nullptr; char* lo = nullptr; int C8 = 0;      // conv2's planes [n][C8][H][W][16 B]; lo == null: f16x1
+    const float* gamma = nullptr; const float* beta = nullptr;
+    const float* film = nullptr; int film_stride = 0, film_off = 0, frows = 0; const StepDev* fstep = nullptr;
+    long long* acc = nullptr;          // [B][32 groups][2] {sum * 2^20, sum of squares * 2^12}, zero before the launch
+    unsigned* cnt = nullptr;           // [B][n_co_blocks] arrival counters, zero before the launch
+    unsigned long long* range_ctr = nullptr;   // f16 operand range guard; a barrier time-out adds 2^40 to it
+};
+
 struct Conv6K {
     const char* xhi; const char* xlo;      // blocked split activations [n][C8][H][W][16 B]
     int C8;
@@ -16,6 +29,7 @@ struct Conv6K {
     float out_scale;
     const float* out_scale_dev;            // optional device scalar multiplied into out_scale (dgrad: undoes the run-time scaling of dY)
     float2* stat; int stat_slots;          // per-(image, channel, slot) {sum, sum of squares} of the stored values, or null
+    Conv6Emit em;                          // em.hi != null: fused emission of the next convolution's operand planes (no fp32 output)
 };
 
 // conv7.hip: every case of launch_conv6 (all three geometries, split-K slabs, f16x1, dgrad scale) with the workgroup tile cut as

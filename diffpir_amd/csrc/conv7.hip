@@ -18,6 +18,7 @@
 // (bench.py, DPIR_CONV7=1/0 interleaved in one call, profiles/r04/bench_ab_conv7_in_one_call.log): 8.34 vs 8.20 images/s.
 // PMC (profiles/r04): matrix pipe busy 78.1 % of the cycles at an effective 1.67 GHz (conv6: 74.8 % at 1.62 GHz).
 #include "common.h"
+#include "elem.h"
 #include "lds_dma.h"
 #include "conv6_params.h"
 #include <type_traits>
@@ -48,7 +49,15 @@ template <> struct Geo7<2> { static constexpr int LTW = 3, LTH = 3, TI = 4; };  
 // NARROW (8 x 32 geometry): a launch with at most 32 output channels (the 128 -> 6 output convolution, the 128 -> 3 dgrad of conv_in).  One
 // live co-tile: instead of two waves computing a dead second co-tile and two waves idling, all four waves take that co-tile for a
 // quarter of the pixels each (wave tile 32 co x 64 px, 6 MFMAs per tap instead of 24 on half the waves).
-template <int GEO, bool X1, bool NARROW>
+// EMIT (8 x 32 geometry, whole K, full 128-channel blocks, tiles inside the image): the fused hop to the next convolution of a ResBlock,
+// see Conv6Emit.  Everything up to the epilogue is the same kernel; workgroups keep their natural order (image-major), so that the
+// <= 256 workgroups of an image are dispatched together and the wait below always ends.
+__device__ __forceinline__ float silu7(float v) {          // act.hip's silu_a
+    float e = __builtin_amdgcn_exp2f(v * -1.4426950408889634f);
+    return v * __builtin_amdgcn_rcpf(1.0f + e);
+}
+
+template <int GEO, bool X1, bool NARROW, bool EMIT>
 __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     using G = Geo7<GEO>;
@@ -64,6 +73,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
     constexpr int CT = NARROW ? 1 : 2;                  // co-tiles (32 channels) per wave
     constexpr int TPG = NARROW ? 1 : 2;                 // pixel tiles (32 pixels) per group; a wave has two groups
     static_assert(!NARROW || GEO == 0, "the narrow variant exists for the 8 x 32 geometry");
+    static_assert(!EMIT || (GEO == 0 && !NARROW), "fused emission exists for the 8 x 32 geometry");
     extern __shared__ __attribute__((aligned(16))) char smem7[];      // [2 buffers][hi|lo][XB]; the epilogue slabs alias it
 
     const int tid = threadIdx.x;
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
     const int half = lane >> 5;
 
     int bid = blockIdx.x;
-    if ((gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous tiles, as conv6
+    if (!EMIT && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous tiles, as conv6
     const int split = bid % p.ksplit;
     bid /= p.ksplit;
     const int co_blk = bid % p.n_co_blocks;
@@ -240,6 +250,148 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
         chunk_body(std::false_type{}, chunk, it);
     }
 
+    if constexpr (EMIT) {
+        // ---- fused emission (Conv6Emit).  Accumulator layout: acc[i][j][r] of lane (l31, half) = channel i*32 + 8*(r>>2) + 4*half + (r&3) of
+        // the wave's 64, pixel (row 4 pw + j, column l31) of the tile.
+        __syncthreads();
+        float* wl = reinterpret_cast<float*>(smem7) + wave * 512;       // per-wave scratch: [0,64) bias, [64,128) S, [128,192) SS, [192,448) table
+        const float osc = p.out_scale;
+        wl[lane] = p.bias[co_wave + lane];
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ch = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const float b = wl[ch];
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float v = acc[i][j][r] * osc + b;
+                    acc[i][j][r] = v;
+                    s1 += v; s2 += v * v;
+                }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 64); s2 += __shfl_xor(s2, o, 64); }      // the 32 lanes of this half
+                if (l31 == 0) { wl[64 + ch] = s1; wl[128 + ch] = s2; }
+            }
+        __builtin_amdgcn_wave_barrier();
+        // GroupNorm needs GROUP sums only, and with integer accumulation the order of the additions is immaterial: fold the channels of a
+        // group and the two pixel halves of the workgroup here, so that ONE atomic instruction per workgroup (<= 32 groups x {S, SS}) is
+        // left.  (Per-channel atomics from every wave -- 512 per workgroup, 2 M per launch -- cost 0.8 ms per forward: profiles/r04.)
+        const int cg = p.Cout >> 5;                           // channels per group: 4, 8 or 16
+        const int gpw = 64 / cg;                              // groups per wave: 16, 8 or 4
+        double* gsum = reinterpret_cast<double*>(reinterpret_cast<float*>(smem7) + 4 * 512);     // [cw 2][pw 2][16 groups][2] behind the per-wave areas
+        if (lane < gpw) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < cg; ++k) { s1 += (double)wl[64 + lane * cg + k]; s2 += (double)wl[128 + lane * cg + k]; }
+            gsum[((cw * 2 + pw) * 16 + lane) * 2] = s1;
+            gsum[((cw * 2 + pw) * 16 + lane) * 2 + 1] = s2;
+        }
+        __syncthreads();
+        const int gpb = 2 * gpw;                              // groups of this workgroup's 128 channels
+        long long* const accb = p.em.acc + ((size_t)n0 * 32 + (size_t)co_blk * gpb) * 2;
+        if (wave == 0) {
+            const int gl = lane >> 1, t = lane & 1;           // lane = (group of the block, S | SS)
+            long long r = 0;
+            if (gl < gpb) {
+                const int c2 = gl / gpw, g = gl - c2 * gpw;
+                const double v = gsum[((c2 * 2 + 0) * 16 + g) * 2 + t] + gsum[((c2 * 2 + 1) * 16 + g) * 2 + t];
+                // memory-side atomic that returns: once the result is back it has been performed (an agent-scope release fence instead
+                // writes back the XCD's dirty L2 lines, i.e. everybody's plane stores: +1.5 ms per forward, profiles/r04)
+                r = __hip_atomic_fetch_add(accb + gl * 2 + t, __double2ll_rn(v * (t ? 4096.0 : 1048576.0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : : "v"((int)r) : "memory");
+            if (lane == 0) {
+                unsigned* cp = p.em.cnt + (size_t)n0 * p.n_co_blocks + co_blk;
+                const unsigned old = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                asm volatile("" : : "v"(old));
+                int spins = 0;
+                while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned)tiles_per_img) {
+                    __builtin_amdgcn_s_sleep(16);
+                    if (++spins > 2000000) { atomicAdd(p.em.range_ctr, 1ull << 40); break; }      // never hang the GPU: report through the range guard
+                }
+            }
+        }
+        __syncthreads();
+        {
+            const int c = co_wave + lane;
+            const long long* ap = accb + (size_t)((cw * gpw) + lane / cg) * 2;
+            const double S = (double)__hip_atomic_load(ap, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * (1.0 / 1048576.0);
+            const double SS = (double)__hip_atomic_load(ap + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) * (1.0 / 4096.0);
+            const double cntd = (double)cg * HW;
+            const double mean = S / cntd;
+            double var = SS / cntd - mean * mean;
+            if (var < 0) var = 0;
+            const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+            float a = rstd * p.em.gamma[c];
+            float b = p.em.beta[c];
+            if (p.em.film) {   // h = GN(h) * (1 + scale) + shift   (unet.py:250-251), gn_prm_kernel's arithmetic
+                const float* f = p.em.film + (p.em.fstep ? (size_t)p.em.fstep->i * p.em.frows : 0) + (size_t)n0 * p.em.film_stride + p.em.film_off;
+                const float sc = 1.0f + f[c];
+                const float sh = f[p.Cout + c];
+                a = a * sc;
+                b = b * sc + sh;
+            }
+            reinterpret_cast<float4*>(wl + 192)[lane] = make_float4((float)mean, a, b, 0.f);
+        }
+        __builtin_amdgcn_wave_barrier();
+        typedef _Float16 half4v __attribute__((ext_vector_type(4)));
+        typedef unsigned int u32x2e __attribute__((ext_vector_type(2)));
+        typedef unsigned int u32x4e __attribute__((ext_vector_type(4)));
+        const float4* tab = reinterpret_cast<const float4*>(wl + 192);
+        bool bad = false;
+        // A 16-byte plane entry = 8 channels of one pixel; this lane holds 4 of them (4 half .. 4 half + 3), lane ^ 32 the other 4.  For a pair
+        // of pixel rows (j, j + 1) v_permlane32_swap hands the lower lanes both halves of row j and the upper lanes both halves of row
+        // j + 1: one 16-byte store per lane (1 KiB per instruction) instead of two 8-byte ones.
+        auto norm_split = [&](float x, const float4& m, _Float16& h, _Float16& l) __attribute__((always_inline)) {
+            float v = (x - m.x) * m.y + m.z;
+            v = silu7(v);
+            bad |= !(fabsf(v) <= 65000.f);
+            v = fminf(fmaxf(v, -65000.f), 65000.f);
+            h = (_Float16)v;
+            l = (_Float16)(v - (float)h);
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int jb = 0; jb < 4; ++jb) {
+                float4 m[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) m[q] = tab[i * 32 + 8 * jb + 4 * half + q];
+                const int c8 = (co_wave + i * 32 + 8 * jb) >> 3;
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) {
+                    half4v h0, l0, h1, l1;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        _Float16 th, tl;
+                        norm_split(acc[i][2 * jp][jb * 4 + q], m[q], th, tl); h0[q] = th; l0[q] = tl;
+                        norm_split(acc[i][2 * jp + 1][jb * 4 + q], m[q], th, tl); h1[q] = th; l1[q] = tl;
+                    }
+                    const u32x2e a_h = __builtin_bit_cast(u32x2e, h0), b_h = __builtin_bit_cast(u32x2e, h1);
+                    const u32x2e a_l = __builtin_bit_cast(u32x2e, l0), b_l = __builtin_bit_cast(u32x2e, l1);
+                    u32x4e eh, el;
+                    {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a_h.x, b_h.x, false, false), s1 = __builtin_amdgcn_permlane32_swap(a_h.y, b_h.y, false, false);
+                        eh.x = s0[0]; eh.y = s1[0]; eh.z = s0[1]; eh.w = s1[1];
+                    }
+                    const size_t eo = (((size_t)n0 * p.em.C8 + c8) * HW + (size_t)(ty0 + 4 * pw + 2 * jp + half) * p.W + (tx0 + l31)) << 4;
+                    *reinterpret_cast<u32x4e*>(p.em.hi + eo) = eh;
+                    if (!X1) {
+                        const auto s0 = __builtin_amdgcn_permlane32_swap(a_l.x, b_l.x, false, false), s1 = __builtin_amdgcn_permlane32_swap(a_l.y, b_l.y, false, false);
+                        el.x = s0[0]; el.y = s1[0]; el.z = s0[1]; el.w = s1[1];
+                        *reinterpret_cast<u32x4e*>(p.em.lo + eo) = el;
+                    }
+                }
+            }
+        {
+            const unsigned long long mk = __ballot(bad);
+            if (mk != 0ull && lane == (int)__builtin_ctzll(mk)) atomicAdd(p.em.range_ctr, (unsigned long long)__builtin_popcountll(mk));
+        }
+        return;
+    }
+
     // ---- epilogue: conv6's (straight-line buffer-descriptor code, see there), four passes q = (co-tile i, pixel-tile pair jp) of
     // 32 co x 64 px: bias, un-scaling, residual in its three forms, GroupNorm partial sums (slot = the 64-pixel group of the tile)
     __syncthreads();
@@ -377,14 +529,14 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
 #endif
 }
 
-template <int GEO, bool X1, bool NARROW = false>
+template <int GEO, bool X1, bool NARROW = false, bool EMIT = false>
 static Status launch7(hipStream_t s, const Conv6K& k, int blocks) {
     using G = Geo7<GEO>;
     constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
     constexpr int NPIECE = (2 * PATCH + 63) / 64;
     constexpr size_t LDS = (size_t)4 * NPIECE * 1024;           // two buffers x (hi, lo); the epilogue slabs (34 KiB) alias them
     static_assert(LDS >= 4 * 32 * 68 * 4, "epilogue slabs");
-    auto fn = conv7_mfma_kernel<GEO, X1, NARROW>;
+    auto fn = conv7_mfma_kernel<GEO, X1, NARROW, EMIT>;
     static LdsAttrOnce attr_set;
     DPIR_HIP(attr_set.set(reinterpret_cast<const void*>(fn), (int)LDS));
     hipLaunchKernelGGL(fn, dim3((unsigned)blocks), dim3(256), LDS, s, k);
@@ -395,6 +547,11 @@ static Status launch7(hipStream_t s, const Conv6K& k, int blocks) {
 Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks, bool x1) {
     if ((k.W & 3) || k.W < 8 || k.H < 8) return invalid("conv7: shape not tiled");
     const int geo = k.W >= 32 ? 0 : (k.W >= 16 ? 1 : 2);
+    if (k.em.hi) {
+        if (geo != 0 || k.ksplit != 1 || (k.Cout & 127) || (k.W & 31) || (k.H & 7) || !k.em.acc || !k.em.cnt || !k.em.range_ctr || (!x1 && !k.em.lo))
+            return invalid("conv7: fused emission needs the 8 x 32 geometry, whole K, full 128-channel blocks and tiles inside the image");
+        return x1 ? launch7<0, true, false, true>(s, k, blocks) : launch7<0, false, false, true>(s, k, blocks);
+    }
     if (geo == 0 && k.Cout <= 32) return x1 ? launch7<0, true, true>(s, k, blocks) : launch7<0, false, true>(s, k, blocks);
     if (x1) {
         if (geo == 0) return launch7<0, true>(s, k, blocks);

@@ -7,6 +7,7 @@
 // attn.hip; concat, pooling, upsampling, GroupNorm-apply, SiLU, FiLM, bias and residual adds never
 // exist as separate passes (see conv.hip).
 #include "engine.h"
+#include "conv6_params.h"
 #include <unordered_map>
 #include <cstdint>
 #include <math.h>
@@ -310,7 +311,7 @@ struct Fwd {
     // low-resolution prologue (gn_act_small) finishes it, or resolve() does -- before anything else reads the tensor or
     // reuses the slab buffer.
     PendingConv pending;
-    bool grad = false;    // grad mode: classic (unfused) prologues, GroupNorm tables kept, tape recorded
+    bool grad = false;    // grad mode: GroupNorm tables kept (also by the fused prologues), tape recorded
     bool fuse_small;
     int emit_skip;        // conv5 emits conv1's operand planes in ResBlocks with a 1x1 skip projection: 0 never, 1 when the projection has
                           // ONE 128-channel output block (each input row is then read exactly once; with two blocks only one of them emits and
@@ -330,7 +331,8 @@ struct Fwd {
     // GroupNorm (+FiLM) + SiLU + 3x3 convolution.  Low-resolution layers on the f16 path take the fused prologue; everything
     // else the separate statistics / gn_prm / act_split (or fp32 in-kernel prologue) route.
     Status gn_conv(const GnW& g, const std::string& tag, int film_off, const ConvW& cw, const Act& in, int mode,
-                   const float* res, int res_mode, float* out, int Ho, int Wo, float4** prm_out = nullptr, float2** stats_out = nullptr) {
+                   const float* res, int res_mode, float* out, int Ho, int Wo, float4** prm_out = nullptr, float2** stats_out = nullptr,
+                   const Conv6Emit* emit = nullptr) {
         const int C = in.C();
         const bool f16path = cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo);
         if (fuse_small && f16path && C == g.c && C % 16 == 0 && gn_act_small_supported(C, in.H, in.W, mode)) {
@@ -351,21 +353,28 @@ struct Fwd {
             ga.fstep = fstep; ga.frows = film_rows;
             ga.silu = true; ga.mode = mode; ga.B = B; ga.Hs = in.H; ga.Ws = in.W;
             ga.hi = s16; ga.lo = x1 ? nullptr : s16 + plane; ga.range_ctr = e->range_ctr;
+            if (grad) {     // the backward pass reads the same tables gn_prm_kernel would have written
+                DPIR_TRY(ws.getT(tag + "#prm", (size_t)B * C, &ga.prm_out));
+                DPIR_TRY(ws.getT(tag + "#gst", (size_t)B * 32, &ga.stats_out));
+                if (prm_out) *prm_out = ga.prm_out;
+                if (stats_out) *stats_out = ga.stats_out;
+            }
             {
                 ProfScope ps(&e->prof, PC_ELEM);
                 DPIR_TRY(launch_gn_act_small(s, ga));
             }
             if (pending.partial) { fused.erase(pending.out); pending = PendingConv{}; }   // finished (and stored) by the fused prologue
-            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo);
+            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo, emit);
         }
         DPIR_TRY(resolve());
         float4* prm = nullptr;
         DPIR_TRY(gn(g, in, tag, film_off, true, &prm, stats_out));
         if (prm_out) *prm_out = prm;
-        return conv(cw, in, mode, prm, res, res_mode, out, Ho, Wo);
+        return conv(cw, in, mode, prm, res, res_mode, out, Ho, Wo, emit);
     }
 
-    Status conv6_on_planes(const ConvW& cw, char* s16, size_t plane, const float* res, int res_mode, float* out, int Ho, int Wo) {
+    Status conv6_on_planes(const ConvW& cw, char* s16, size_t plane, const float* res, int res_mode, float* out, int Ho, int Wo,
+                           const Conv6Emit* emit = nullptr) {
         const bool x1 = e->precision == 2;
         Conv6Args a6;
         a6.x1 = x1;
@@ -381,6 +390,8 @@ struct Fwd {
             DPIR_TRY(ws.getT("sp#" + key, (size_t)B * cw.cout, &sp));
         }
         a6.stat = st; a6.stat_plane = sp;
+        a6.emit = emit;
+        if (emit) { a6.stat = nullptr; a6.stat_plane = nullptr; a6.partial = nullptr; a6.partial_capacity = 0; }
         int kind = 0;
         PendingConv pc;
         ProfScope ps(&e->prof, PC_CONV3);
@@ -392,7 +403,8 @@ struct Fwd {
         return Status{};
     }
 
-    Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo) {
+    Status conv(const ConvW& cw, const Act& in, int mode, const float4* prm, const float* res, int res_mode, float* out, int Ho, int Wo,
+                const Conv6Emit* emit = nullptr) {
         const bool x1 = e->precision == 2;        // f16x1: single-product mode, hi halves only
         // an unfinished split-K output is finished before anything but the fused prologue reads it (or reuses the slab buffer)
         const bool use5 = cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo, prm != nullptr) &&
@@ -413,8 +425,9 @@ struct Fwd {
                 ProfScope ps(&e->prof, PC_ELEM);
                 DPIR_TRY(launch_act_split(s, CatSrc{in.a, in.ca, in.b, in.cb}, prm, mode, B, Ho, Wo, s16, x1 ? nullptr : s16 + plane, e->range_ctr));
             }
-            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo);
+            return conv6_on_planes(cw, s16, plane, res, res_mode, out, Ho, Wo, emit);
         }
+        if (emit) return invalid("conv: fused emission was requested for a launch that is not on the f16 3x3 path");
         if (use5) {
             Conv5Args a5;
             a5.src = CatSrc{in.a, in.ca, in.b, in.cb}; a5.prm = prm; a5.w16 = cw.w16; a5.w16_scale = cw.w16_scale;
@@ -464,6 +477,32 @@ struct Fwd {
         if (e->collect_taps) e->taps[name] = TapInfo{p, numel};
     }
 
+    // The hop conv1 -> GroupNorm + FiLM + SiLU -> conv2 without h1 (Conv6Emit): conv1's epilogue writes conv2's operand planes.
+    // Accumulators / arrival counters of all fused layers of a forward live in one arena, zeroed once per forward.
+    bool fuse_h1 = true;
+    long long* fuse_arena = nullptr; size_t fuse_cap = 0, fuse_off = 0;       // in 8-byte words
+    bool h1_fusable(const ResW& r, int Ho, int Wo) const {
+        return fuse_h1 && !grad && e->precision != 0 && r.conv1.w16 && r.conv2.w16 && r.conv1.ks == 3 && r.conv2.ks == 3 && r.gn2.c == r.cout &&
+               conv7_emit_supported(B, r.cout, Ho, Wo) && fuse_arena && fuse_off + (size_t)B * 64 + (size_t)B * (r.cout / 128) <= fuse_cap &&
+               (size_t)B * (2 * ((r.cout + 15) / 16)) * Ho * Wo * 16 < ((size_t)1 << 32);
+    }
+    Status make_emit(const ResW& r, int Ho, int Wo, Conv6Emit* em, char** s16b, size_t* plane2) {
+        const bool x1 = e->precision == 2;
+        const int C8 = 2 * ((r.cout + 15) / 16);
+        *plane2 = (size_t)B * C8 * Ho * Wo * 16;
+        DPIR_TRY(ws.getT("act#s16b", 2 * *plane2, s16b));
+        em->hi = *s16b; em->lo = x1 ? nullptr : *s16b + *plane2; em->C8 = C8;
+        em->gamma = r.gn2.gamma; em->beta = r.gn2.beta;
+        em->film = r.film_off >= 0 ? film : nullptr; em->film_stride = film_stride; em->film_off = r.film_off < 0 ? 0 : r.film_off;
+        em->frows = film_rows; em->fstep = fstep;
+        em->acc = fuse_arena + fuse_off;
+        fuse_off += (size_t)B * 64;                     // [B][32 groups][2]
+        em->cnt = reinterpret_cast<unsigned*>(fuse_arena + fuse_off);
+        fuse_off += ((size_t)B * (r.cout / 128) + 1) / 2;
+        em->range_ctr = e->range_ctr;
+        return Status{};
+    }
+
     Status resblock(const ResW& r, const Act& in, Act* out) {
         if (in.C() != r.cin) return invalid("resblock " + r.name + ": input channels mismatch");
         int Ho = r.mode == 1 ? in.H * 2 : (r.mode == 2 ? in.H / 2 : in.H);
@@ -482,8 +521,10 @@ struct Fwd {
             Cin % 16 == 0 && Cin <= kConv5EmitMaxC && (Ho * Wo) % 256 == 0 && eplane < ((size_t)1 << 32) && !(fuse_small && gn_act_small_supported(Cin, in.H, in.W, 0))) {
             const bool x1 = e->precision == 2;
             float4* prm1 = nullptr;
+            TapeRes tr{};
             DPIR_TRY(resolve());
-            DPIR_TRY(gn(r.gn1, in, r.name + "#gn1", -1, true, &prm1));
+            DPIR_TRY(gn(r.gn1, in, r.name + "#gn1", -1, true, &prm1, &tr.st1));
+            tr.prm1 = prm1;
             char* s16 = nullptr;
             DPIR_TRY(ws.getT("act#s16", 2 * eplane, &s16));
             float* sk = nullptr;
@@ -498,21 +539,40 @@ struct Fwd {
                 ProfScope ps(&e->prof, PC_CONV1);
                 DPIR_TRY(launch_conv5(s, a5));
             }
-            DPIR_TRY(conv6_on_planes(r.conv1, s16, eplane, nullptr, 0, h1, Ho, Wo));
-            tap(r.name + "#h1", h1, on);
             float* o = nullptr;
             DPIR_TRY(ws.getT(r.name + "#out", on, &o));
-            DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, sk, 0, o, Ho, Wo));
+            if (h1_fusable(r, Ho, Wo)) {
+                Conv6Emit em; char* s16b = nullptr; size_t plane2 = 0;
+                DPIR_TRY(make_emit(r, Ho, Wo, &em, &s16b, &plane2));
+                DPIR_TRY(conv6_on_planes(r.conv1, s16, eplane, nullptr, 0, nullptr, Ho, Wo, &em));
+                DPIR_TRY(conv6_on_planes(r.conv2, s16b, plane2, sk, 0, o, Ho, Wo));
+            } else {
+                DPIR_TRY(conv6_on_planes(r.conv1, s16, eplane, nullptr, 0, h1, Ho, Wo));
+                tap(r.name + "#h1", h1, on);
+                DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, sk, 0, o, Ho, Wo, &tr.prm2, &tr.st2));
+            }
             tap(r.name, o, on);
+            if (grad) {
+                tr.idx = (int)(&r - e->net.res.data());
+                tr.in = CatSrc{in.a, in.ca, in.b, in.cb}; tr.inH = in.H; tr.inW = in.W; tr.Ho = Ho; tr.Wo = Wo; tr.h1 = h1; tr.sk = sk; tr.out = o;
+                e->tape.nodes.push_back(TapeNode{1, (int)e->tape.res.size()});
+                e->tape.res.push_back(tr);
+            }
             out->a = o; out->ca = r.cout; out->b = nullptr; out->cb = 0; out->H = Ho; out->W = Wo;
             return Status{};
         }
         TapeRes tr{};
-        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, h1, Ho, Wo, &tr.prm1, &tr.st1));
-        tap(r.name + "#h1", h1, on);
+        // (Measured dead end, round 4: forking the 1x1 skip projection onto a side stream -- a parallel branch of the captured step graph --
+        // so that it runs under conv1: 19.47 / 19.51 ms per forward with it against 19.28 / 19.30 without, 8.28-8.30 images/s either way;
+        // profiles/r04/dead_end_side_stream_skip_*.log.)
+        float* sk = nullptr;
+        if (r.has_skip) DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
+        const bool fuse = h1_fusable(r, Ho, Wo);
+        Conv6Emit em; char* s16b = nullptr; size_t plane2 = 0;
+        if (fuse) DPIR_TRY(make_emit(r, Ho, Wo, &em, &s16b, &plane2));
+        DPIR_TRY(gn_conv(r.gn1, r.name + "#gn1", -1, r.conv1, in, r.mode, nullptr, 0, fuse ? nullptr : h1, Ho, Wo, &tr.prm1, &tr.st1, fuse ? &em : nullptr));
+        if (!fuse) tap(r.name + "#h1", h1, on);
         if (r.has_skip) {
-            float* sk = nullptr;
-            DPIR_TRY(ws.getT(r.name + "#skip", on, &sk));
             DPIR_TRY(conv(r.skip, in, 0, nullptr, nullptr, 0, sk, Ho, Wo));
             res = sk;
             tr.sk = sk;
@@ -522,7 +582,8 @@ struct Fwd {
         }
         float* o = nullptr;
         DPIR_TRY(ws.getT(r.name + "#out", on, &o));
-        DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, res, res_mode, o, Ho, Wo, &tr.prm2, &tr.st2));
+        if (fuse) DPIR_TRY(conv6_on_planes(r.conv2, s16b, plane2, res, res_mode, o, Ho, Wo));
+        else DPIR_TRY(gn_conv(r.gn2, r.name + "#gn2", r.film_off, r.conv2, h1a, 0, res, res_mode, o, Ho, Wo, &tr.prm2, &tr.st2));
         tap(r.name, o, on);
         if (grad) {
             tr.idx = (int)(&r - e->net.res.data());
@@ -625,8 +686,16 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
         static const int emit_env = getenv("DPIR_EMIT_SKIP") ? atoi(getenv("DPIR_EMIT_SKIP")) : 1;
         f.grad = e->grad_enabled;
-        f.fuse_small = fuse_env && !f.grad;
-        f.emit_skip = f.grad ? 0 : emit_env;
+        // gradient mode keeps the fused prologues (round 4): gn_act_small leaves the {mean, a, b, act} / {mean, rstd} tables the backward reads
+        f.fuse_small = fuse_env;
+        f.emit_skip = emit_env;
+        static const bool fuse_h1_env = !(getenv("DPIR_FUSE_H1") && atoi(getenv("DPIR_FUSE_H1")) == 0);
+        f.fuse_h1 = fuse_h1_env && !f.grad && e->precision != 0;
+        if (f.fuse_h1) {       // accumulators + arrival counters of the fused conv1 -> conv2 hops: one arena, zeroed once per forward
+            f.fuse_cap = (size_t)B * 4096;         // 8-byte words: room for ~60 fused hops of (64 + Cout / 128) words per image
+            DPIR_TRY(ws.getT("fuse#arena", f.fuse_cap, &f.fuse_arena));
+            DPIR_HIP(hipMemsetAsync(f.fuse_arena, 0, f.fuse_cap * sizeof(long long), s));
+        }
         if (f.grad) { e->tape.clear(); e->tape.B = B; e->tape.H = H; e->tape.W = W; }
     }
     if (e->collect_taps) e->taps.clear();

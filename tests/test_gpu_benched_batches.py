@@ -86,3 +86,44 @@ def test_c4_motion_loop_at_the_per_gpu_batch_b32_4nfe(ffhq):
         gpu_common._ORACLE_CACHE[key] = (ref, exact)
     ref, exact = gpu_common._ORACLE_CACHE[key]
     fft_prox_parity(out[sub], ref, case["gt"][sub], f"C4 motion B=32 4-NFE, images 7 and 30 [{precision}] vs oracle", exact=exact)
+
+
+_FUSE_SNIPPET = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, {root!r})
+import diffpir_amd
+from oracle import unet_oracle as uo
+from tests.gpu_common import make_model
+e = diffpir_amd.Engine(0); e.set_precision({precision!r})
+make_model(e, uo.ffhq_hp())
+g = torch.Generator().manual_seed(77)
+x = torch.randn((16, 3, 256, 256), generator=g); t = torch.randint(0, 1000, (16,), generator=g)
+xd = e.to_device(x.numpy())
+a = e.unet_forward(xd, t.numpy()).numpy()
+b = e.unet_forward(xd, t.numpy()).numpy()
+assert np.array_equal(a, b), "two forwards of the same input differ"
+np.save({out!r}, a)
+"""
+
+
+@pytest.mark.parametrize("precision", ["f16x3", "f16x1"])
+def test_fused_h1_hop_is_reproducible_and_equals_the_unfused_path(tmp_path, precision):
+    """conv7's fused hop conv1 -> GroupNorm + FiLM + SiLU -> conv2 (Conv6Emit: per-image integer accumulators, arrival counter, planes
+    written by conv1's epilogue; on for every ResBlock at >= 64^2 when B = 16) against the same forward with DPIR_FUSE_H1=0 (fp32 h1,
+    gn_prm, act_split): two forwards in one process are bit-identical (integer accumulation is order-independent), and the two paths
+    agree to the level of the GroupNorm statistics' summation order."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = {}
+    for fuse in ("1", "0"):
+        out = str(tmp_path / f"fwd_{fuse}.npy")
+        env = dict(os.environ, DPIR_FUSE_H1=fuse)
+        r = subprocess.run([sys.executable, "-c", _FUSE_SNIPPET.format(root=root, precision=precision, out=out)], cwd=root, env=env,
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        outs[fuse] = np.load(out)
+    err = rel_err(outs["1"], outs["0"])
+    print(f"fused h1 hop vs unfused, FFHQ 256^2 B=16 [{precision}]: rel err {err:.3e}")
+    assert err < (5e-6 if precision == "f16x3" else 2e-3)
