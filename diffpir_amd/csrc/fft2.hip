@@ -310,21 +310,9 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
     float2 v[RJ];
 #pragma unroll
     for (int n1 = 0; n1 < RJ; ++n1) v[n1] = base[(size_t)(R * n1 + t) * WP];
-    // sf = 1 solve: its three spectra do not depend on the transform -- requested together with the data (one memory round trip instead of
-    // a second one between the forward and the inverse transform); RJ <= 16 keeps this at 5 * RJ extra registers
-    constexpr bool PRE = MODE == 2 && RJ <= 16;
-    float2 pFB[PRE ? RJ : 1], pFy[PRE ? RJ : 1]; float pF2[PRE ? RJ : 1];
-    if (PRE) {
-        const int n_img = plane / 3;
-        const float2* FB = a.FB + (size_t)n_img * N * WP + col;
-        const float* F2B = a.F2B + (size_t)n_img * N * WP + col;
-        const float2* FBFy = a.FBFy + (size_t)plane * N * WP + col;
-#pragma unroll
-        for (int k2 = 0; k2 < (PRE ? RJ : 1); ++k2) {
-            const size_t off = (size_t)(t + R * k2) * WP;
-            pFB[k2] = FB[off]; pFy[k2] = FBFy[off]; pF2[k2] = F2B[off];
-        }
-    }
+    // (Requesting the solve's three spectra here as well, so that they travel with the data, made this kernel 10 % SLOWER -- 38.9 vs 35.2 us
+    // per apply, three times in one call, profiles/r04/dead_end_prox_cols_operand_prefetch_ab.log: 64 loads in flight per thread delay the
+    // 16 the transform is waiting for.  They are loaded after the forward transform, as in round 3.)
 #pragma unroll
     for (int j = 0; j < NTW; ++j) { const int i = threadIdx.x + j * THREADS; if (i < N) twN[i] = twr[j]; }
     __syncthreads();
@@ -338,10 +326,10 @@ __global__ __launch_bounds__(THREADS) void cfft_cols_kernel(float2* buf, SolveAr
 #pragma unroll
         for (int k2 = 0; k2 < RJ; ++k2) {
             size_t off = (size_t)(t + R * k2) * WP;
-            float2 fr = cadd(PRE ? pFy[k2] : FBFy[off], v[k2]);
-            float2 fb = PRE ? pFB[k2] : FB[off];
+            float2 fr = cadd(FBFy[off], v[k2]);
+            float2 fb = FB[off];
             float2 x1 = cmul2(fb, fr);
-            float den = (PRE ? pF2[k2] : F2B[off]) + alpha;
+            float den = F2B[off] + alpha;
             float2 q = make_float2(x1.x / den, x1.y / den);
             float2 tq = cmulc2(q, fb);                          // conj(FB) * q
             v[k2] = make_float2((fr.x - tq.x) / alpha, (fr.y - tq.y) / alpha);
