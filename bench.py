@@ -123,7 +123,10 @@ def conv_roofline(eng, B, H, precision, model_name):
     peak = {"f32": PEAK_FP32_MFMA_TFLOPS, "f16x1": 2500.0}.get(precision, PEAK_F16X3_TFLOPS)
     kern = ("conv2_mfma_kernel<3x3> (v_mfma_f32_32x32x2_f32, exact fp32)" if precision == "f32" else
             "conv6_mfma_kernel<3x3, X1> (one v_mfma_f32_32x32x16_f16 per product, hi planes only; two workgroups per CU)" if precision == "f16x1" else
-            "3x3 class: conv7_mfma_kernel<geometry, f16x3> (64 co x 128 px per wave, weights straight into registers; + conv6_mfma_kernel for the split-K launches of the 8x32 geometry and the 128->6 output convolution) "
+            "3x3 class: conv7_mfma_kernel<geometry, f16x3> (64 co x 128 px per wave, weights straight into registers; the plane-emitting variant of every "
+            "ResBlock's conv1 also carries GroupNorm statistics, the per-image wait, FiLM + SiLU and the f16 split of conv2's operands -- that work and "
+            "wait are inside this class's time since round 4, which is why the class fraction fell while the UNet step rose; + conv6_mfma_kernel for the "
+            "split-K launches of the 8x32 geometry) "
             "(3 x v_mfma_f32_32x32x16_f16 per fp32-equivalent product; operands pre-split by act_split*_kernel; two workgroups per CU)")
     step_fl = eng.unet_flops(H, H) * B
     tr = PMC_TRAFFIC.get(f"{model_name}_B{B}_{H}_{precision}")
