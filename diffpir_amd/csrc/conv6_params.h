@@ -14,6 +14,8 @@ struct Conv6Emit {
     long long* acc = nullptr;          // [B][32 groups][2] {sum * 2^20, sum of squares * 2^12}, zero before the launch
     unsigned* cnt = nullptr;           // [B][n_co_blocks] arrival counters, zero before the launch
     unsigned long long* range_ctr = nullptr;   // f16 operand range guard; a barrier time-out adds 2^40 to it
+    int spin_limit = 2000000;          // polls (~0.5 us each) before a waiting workgroup gives up and flags the guard word
+    int expect_extra = 0;              // tests only (DPIR_FUSE_EXPECT_EXTRA): arrivals waited for beyond the image's workgroups -> forces the time-out
 };
 
 struct Conv6K {

@@ -307,9 +307,9 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
                 const unsigned old = __hip_atomic_fetch_add(cp, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 asm volatile("" : : "v"(old));
                 int spins = 0;
-                while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned)tiles_per_img) {
+                while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned)(tiles_per_img + p.em.expect_extra)) {
                     __builtin_amdgcn_s_sleep(16);
-                    if (++spins > 2000000) { atomicAdd(p.em.range_ctr, 1ull << 40); break; }      // never hang the GPU: report through the range guard
+                    if (++spins > p.em.spin_limit) { atomicAdd(p.em.range_ctr, 1ull << 40); break; }      // never hang the GPU: report through the range guard
                 }
             }
         }

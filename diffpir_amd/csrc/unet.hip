@@ -500,6 +500,11 @@ struct Fwd {
         em->cnt = reinterpret_cast<unsigned*>(fuse_arena + fuse_off);
         fuse_off += ((size_t)B * (r.cout / 128) + 1) / 2;
         em->range_ctr = e->range_ctr;
+        // test hooks for the time-out path (tests/test_gpu_benched_batches.py): a short spin limit and an arrival count that cannot be reached
+        static const int spin_env = getenv("DPIR_FUSE_SPIN_LIMIT") ? atoi(getenv("DPIR_FUSE_SPIN_LIMIT")) : 0;
+        static const int extra_env = getenv("DPIR_FUSE_EXPECT_EXTRA") ? atoi(getenv("DPIR_FUSE_EXPECT_EXTRA")) : 0;
+        if (spin_env > 0) em->spin_limit = spin_env;
+        em->expect_extra = extra_env;
         return Status{};
     }
 

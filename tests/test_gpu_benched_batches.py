@@ -127,3 +127,41 @@ def test_fused_h1_hop_is_reproducible_and_equals_the_unfused_path(tmp_path, prec
     err = rel_err(outs["1"], outs["0"])
     print(f"fused h1 hop vs unfused, FFHQ 256^2 B=16 [{precision}]: rel err {err:.3e}")
     assert err < (5e-6 if precision == "f16x3" else 2e-3)
+
+
+_TIMEOUT_SNIPPET = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+import diffpir_amd
+from oracle import unet_oracle as uo
+from tests.gpu_common import make_model
+e = diffpir_amd.Engine(0); e.set_precision("f16x3")
+make_model(e, uo.ffhq_hp())
+x = e.to_device(np.random.default_rng(0).standard_normal((16, 3, 256, 256)).astype(np.float32))
+try:
+    e.unet_forward(x, np.full(16, 500)).numpy()
+    print("NO ERROR")
+except diffpir_amd.EngineError as ex:
+    print("ENGINE ERROR:", ex)
+try:
+    e.sync()
+    print("SECOND SYNC OK")
+except diffpir_amd.EngineError as ex:
+    print("STICKY:", ex)
+"""
+
+
+def test_fused_h1_hop_gives_up_loudly_instead_of_hanging():
+    """The fused hop's workgroups wait for one another.  Should that wait ever not end (it cannot on an engine that has the GPU to itself:
+    DESIGN 3.1), a workgroup must give up and the engine must FAIL, never hang the GPU or return an image.  Forced here with the test
+    hooks: an arrival count that cannot be reached and a short spin limit."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, DPIR_FUSE_EXPECT_EXTRA="1", DPIR_FUSE_SPIN_LIMIT="300")
+    r = subprocess.run([sys.executable, "-c", _TIMEOUT_SNIPPET.format(root=root)], cwd=root, env=env, capture_output=True, text=True, timeout=300)
+    out = r.stdout + r.stderr
+    assert r.returncode == 0, out[-2000:]
+    assert "ENGINE ERROR:" in out and "waited too long" in out, out[-2000:]
+    assert "STICKY:" in out, out[-2000:]           # the results stay invalid until the next forward starts a new accounting period
