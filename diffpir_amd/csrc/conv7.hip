@@ -15,7 +15,7 @@
 // Measured back to back against conv6 on one box (profiles/r04/conv7x_check.log): x1.03-1.06 at 256^2 / 128^2, x1.03 in f16x1 and with
 // the dgrad scale, x1.01-1.08 at 16 x 16 / 8 x 8 -- and x0.93 for the split-K launches of the 8 x 32 geometry, x0.95 for the 128 -> 6
 // output convolution (one live co-tile of four): those two launch classes stay on conv6 (launch_conv6 decides).  In the loop
-// (bench.py, DPIR_CONV7=1/0 interleaved in one call, profiles/r04/bench_ab_conv7_in_one_call.log): 8.34 vs 8.20 images/s.
+// (bench.py, DPIR_CONV7=1/0 interleaved in one call, profiles/r04/bench_ab_conv7_in_one_call.log): 8.37 / 8.32 vs 8.19 / 8.21 images/s (the round-3 kernel on / off).
 // PMC (profiles/r04): matrix pipe busy 78.1 % of the cycles at an effective 1.67 GHz (conv6: 74.8 % at 1.62 GHz).
 #include "common.h"
 #include "elem.h"
