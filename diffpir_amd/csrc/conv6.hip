@@ -520,11 +520,12 @@ static int conv6_geo(int H, int W) {
 }
 bool conv6_supported(int H, int W) { return conv6_geo(H, W) >= 0; }
 // Conv6Emit: whole K (>= 384 workgroups, launch_conv6's rule), 8 x 32 tiles inside the image, full 128-channel blocks, and at most 256
-// workgroups per image so that an image's workgroups are resident together (two images fill the chip's 512 slots)
+// workgroups per (image, co-block) -- the set that waits for one another, consecutive in dispatch order -- so that it is resident
+// together with room to spare (the chip holds 512)
 bool conv7_emit_supported(int B, int Cout, int H, int W) {
     if (conv6_geo(H, W) != 0 || (W & 31) || (H & 7) || (Cout & 127)) return false;
-    const int per_img = (W / 32) * (H / 8) * (Cout / 128);
-    return per_img <= 256 && per_img * B >= 384;
+    const int tiles = (W / 32) * (H / 8);
+    return tiles <= 256 && tiles * (Cout / 128) * B >= 384;
 }
 
 // statistics slots per (image, channel) plane written by the epilogue when no split-K is used

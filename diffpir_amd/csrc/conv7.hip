@@ -88,9 +88,12 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
     if (!EMIT && (gridDim.x & 7) == 0) bid = (bid & 7) * (gridDim.x >> 3) + (bid >> 3);      // XCD-contiguous tiles, as conv6
     const int split = bid % p.ksplit;
     bid /= p.ksplit;
-    const int co_blk = bid % p.n_co_blocks;
-    const int ptile = bid / p.n_co_blocks;
     const int tiles_per_img = p.tiles_x * p.tiles_y;
+    // EMIT: inside an image the co-block is the OUTER index, so that the workgroups that wait for one another -- one (image, co-block):
+    // GroupNorm groups never straddle a 128-channel block -- are tiles_per_img (<= 256) CONSECUTIVE ids, whatever the channel count
+    const int per_img = tiles_per_img * p.n_co_blocks;
+    const int co_blk = EMIT ? (bid % per_img) / tiles_per_img : bid % p.n_co_blocks;
+    const int ptile = EMIT ? (bid / per_img) * tiles_per_img + (bid % per_img) % tiles_per_img : bid / p.n_co_blocks;
     const int img_grp = ptile / tiles_per_img;
     const int n0 = img_grp * TI;
     const int trem = ptile - img_grp * tiles_per_img;
