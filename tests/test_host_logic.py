@@ -260,3 +260,26 @@ def test_t_start_and_duplicate_final_steps_in_the_engine_step_table():
     restore._steps(restore.LoopConfig(task="deblur", iter_num=100, skip_noise_model_t=True))
     with pytest.raises(NotImplementedError):
         restore._steps(restore.LoopConfig(task="deblur", iter_num=999, skip_noise_model_t=True))
+
+
+@pytest.mark.parametrize("mode", ["DPS_y0", "DPS_yt"])
+def test_dps_host_noise_draw_order_matches_the_oracle_loop(mode):
+    """restore.dps_host_noise_shapes -- what the YAML driver pre-draws (and what a rank with an empty shard consumes to keep the shared
+    generator in step) -- is the sequence of randn_like shapes the reference's DPS loop requests: init, then per step the sampler's draw
+    (also on the dead final step) and, DPS_yt on non-final steps, the y_t draw (main_ddpir.py:315, 371-373, 440; gaussian_diffusion.py:430)."""
+    from diffpir_amd import restore
+    from oracle import unet_oracle as uo, diffpir_oracle as do
+    hp = uo.tiny_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    B, h, sf, nfe = 1, 16, 4, 4
+    kw = dict(noise_init_img=100.0) if mode == "DPS_yt" else {}
+    ocfg = do.LoopConfig("sr", nfe, 12.75 / 255, 6.0, 0.25, sf=sf, sr_mode="cubic", generate_mode=mode, **kw)
+    seen = []
+
+    def nf(like):
+        seen.append(tuple(like.shape))
+        return torch.zeros(like.shape)
+    do.restore_dps_y0(sd, hp, ocfg, torch.rand((B, 3, h, h)), noise_fn=nf)
+    cfg = restore.LoopConfig(task="sr", iter_num=nfe, lambda_=6.0, zeta=0.25, sf=sf, sr_mode="cubic", generate_mode=mode, **kw)
+    _, steps, _ = restore._steps(cfg)
+    assert restore.dps_host_noise_shapes(cfg, steps, B, h * sf, h * sf) == seen
