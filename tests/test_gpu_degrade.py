@@ -71,6 +71,21 @@ def test_yaml_driver_runs_end_to_end_on_the_device(tmp_path):
     assert len(res) == 1 and np.isfinite(res[0])
 
 
+@pytest.mark.parametrize("mode,ddim", [("DPS_y0", False), ("DPS_yt", True)])
+def test_yaml_driver_runs_the_dps_modes_with_host_noise(tmp_path, mode, ddim):
+    """generate_mode DPS_y0 / DPS_yt through the YAML driver with engine_noise: host (round-3 advisor: the driver pre-drew the DiffPIR
+    loop's noise and the DPS path then refused it) -- the DPS modes pull their own draw order through noise_fn; ddim_sample reaches the loop."""
+    import yaml
+    from diffpir_amd import main_ddpir
+    cfg = yaml.safe_load(open("configs/engine_example.yaml"))
+    cfg.update(iter_num=3, batch_size=2, task="sr", sf=4, sr_mode="cubic", generate_mode=mode, ddim_sample=ddim, engine_noise="host",
+               noise_init_img=100.0 if mode == "DPS_yt" else "max")
+    p = tmp_path / "c.yaml"
+    p.write_text(yaml.safe_dump(cfg))
+    res = main_ddpir.main(["--opt", str(p), "--synthetic", "2", "--max-sweeps", "1"])
+    assert len(res) == 1 and np.isfinite(res[0])
+
+
 def test_f16x1_mode_quality_contract():
     """precision 'f16x1' (SURVEY.md 8f-2): f16 operands, ONE MFMA per product, fp32 accumulation and fp32 GroupNorm / softmax /
     residual stream -- the reference's use_fp16 recipe.  It is a reduced-precision mode: NOT held to the 1e-3 dB parity bar, but
