@@ -1104,7 +1104,8 @@ int dpir_run_dps_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step*
         float *gup = nullptr, *normv = nullptr;
         if (variant == 1) {
             // DPS_yt (main_ddpir.py:439-445): the measurement is noised to level t, the residual is taken at xt = p_sample's sample and
-            // differentiated w.r.t. xt itself -- no backward through the network (the norm cancels: no cross-rank exchange needed)
+            // differentiated w.r.t. xt itself -- no backward through the network.  The norm is multiplied back in (:444); it is still the
+            // whole batch's (all-reduced in dps_norm when a communicator is attached), so the last bit does not depend on the sharding
             const float* ny = noise_yt_dev ? noise_yt_dev + (size_t)i * small : nullptr;
             if (!ny) { API_TRY(e, launch_randn(s, diff, d.seed, (uint64_t)4 * (i + 1) + 1, d.image_offset, B, (size_t)3 * h * w)); ny = diff; }
             float* nyb = nullptr;

@@ -289,14 +289,20 @@ def check_dps_sharding(engine, cfg, n_images: int, world: int):
     """generate_mode DPS_y0 is the ONE mode that couples the images of a batch: grad_and_value takes the norm over the whole batch
     (utils/utils_model.py:392) and the update `x = xt - norm_grad` (main_ddpir.py:437) has no `* norm` factor that would cancel it.
     Sharded, every rank's loop therefore all-reduces the squared residual sums over the communicator (csrc/api.hip `dps_norm`) -- which
-    needs the C ABI's RCCL communicator on the engine and every rank inside the loop (no empty shard)."""
-    if world <= 1 or getattr(cfg, "generate_mode", "") != "DPS_y0":
+    needs the C ABI's RCCL communicator on the engine and every rank inside the loop (no empty shard).
+
+    DPS_yt multiplies the norm back in (main_ddpir.py:444), so it is correct without any exchange -- but with a communicator attached
+    its loop all-reduces the same sums (the whole batch's norm, as the reference has it: results do not depend on the sharding even in
+    the last bit), so an empty shard would leave the other ranks waiting in that collective: refused as well."""
+    mode = getattr(cfg, "generate_mode", "")
+    if world <= 1 or mode not in ("DPS_y0", "DPS_yt"):
         return
-    if not getattr(engine, "rccl", False):
+    rccl = getattr(engine, "rccl", False)
+    if mode == "DPS_y0" and not rccl:
         raise NotImplementedError("generate_mode DPS_y0 on several GPUs needs the default 'rccl' collective: the batch-wide residual norm is all-reduced "
                                   "inside the loop through the engine's communicator (torch.distributed fallbacks cannot reach into the loop)")
-    if n_images < world:
-        raise NotImplementedError(f"generate_mode DPS_y0: a batch of {n_images} images cannot be sharded over {world} ranks (every rank must run the loop: "
+    if rccl and n_images < world:
+        raise NotImplementedError(f"generate_mode {mode}: a batch of {n_images} images cannot be sharded over {world} ranks (every rank must run the loop: "
                                   "its all-reduce of the batch norm is collective)")
 
 

@@ -177,3 +177,10 @@ def test_dps_y0_sharding_needs_the_in_loop_allreduce():
     ddist.check_dps_sharding(E(), cfg, 8, 2)
     with pytest.raises(NotImplementedError, match="every rank"):
         ddist.check_dps_sharding(E(), cfg, 1, 2)
+    # DPS_yt with the communicator attached all-reduces the same sums: an empty shard would hang the other ranks
+    yt = restore.LoopConfig(task="sr", sf=4, generate_mode="DPS_yt")
+    ddist.check_dps_sharding(E(), yt, 8, 2)
+    with pytest.raises(NotImplementedError, match="every rank"):
+        ddist.check_dps_sharding(E(), yt, 1, 2)
+    E.rccl = False
+    ddist.check_dps_sharding(E(), yt, 1, 2)                                    # torch.distributed fallbacks: no in-loop collective
