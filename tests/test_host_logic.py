@@ -283,3 +283,26 @@ def test_dps_host_noise_draw_order_matches_the_oracle_loop(mode):
     cfg = restore.LoopConfig(task="sr", iter_num=nfe, lambda_=6.0, zeta=0.25, sf=sf, sr_mode="cubic", generate_mode=mode, **kw)
     _, steps, _ = restore._steps(cfg)
     assert restore.dps_host_noise_shapes(cfg, steps, B, h * sf, h * sf) == seen
+
+
+def test_gradient_mode_plugs_refuse_what_they_cannot_do_before_touching_the_device():
+    """The argument errors of the round-4 plugs (model_fn output types, grad_and_value operators, Resizer factors) are host-side."""
+    from diffpir_amd import utils_model
+    from diffpir_amd.utils_resizer import Resizer
+    with pytest.raises(ValueError, match="model_out_type"):
+        utils_model.model_fn(None, 10.0, None, model_out_type="pred_nonsense", alphas_cumprod=np.linspace(0.99, 0.01, 1000))
+    with pytest.raises(NotImplementedError, match="Resizer"):
+        utils_model.grad_and_value(operator=lambda v: v, x=None, x_hat=None, measurement=None)
+    with pytest.raises(NotImplementedError, match="integer factor"):
+        Resizer((1, 3, 64, 64), 1 / 2.5)
+    assert Resizer((1, 3, 64, 64), 1 / 4).sf == 4 and Resizer((1, 3, 64, 64), 0.5).to("cuda").sf == 2
+    # per-sample timesteps / 'epsilon' with vec_t: the reference reads an undefined t_step there (utils_model.py:248, 252)
+
+    class D:
+        sqrt_recip_alphas_cumprod = np.ones(1000)
+        sqrt_recipm1_alphas_cumprod = np.ones(1000)
+    ac = np.linspace(0.999, 0.001, 1000)
+    with pytest.raises(NameError):
+        utils_model.model_fn(None, 10.0, None, vec_t=np.array([5, 5]), model_out_type="epsilon", diffusion=D, alphas_cumprod=ac)
+    with pytest.raises(NotImplementedError, match="per-sample"):
+        utils_model.model_fn(None, 10.0, None, vec_t=np.array([5, 6]), model_out_type="pred_xstart", diffusion=D, alphas_cumprod=ac)
