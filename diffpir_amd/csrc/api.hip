@@ -39,8 +39,9 @@ int dpir_check_range(dpir_engine* e) {
         return fail(e, Status{DPIR_ERR_HIP, "reading the operand range counter failed"});
     if (n == 0) return DPIR_OK;
     if (n >= (1ull << 40))      // conv7's fused GroupNorm hop (Conv6Emit): a workgroup gave up waiting for its image's statistics
-        return fail(e, Status{DPIR_ERR_HIP, "conv7 fused emission: a workgroup waited too long for the other workgroups of its image (results are invalid); "
-                                            "set DPIR_FUSE_H1=0 and report the launch shape"});
+        return fail(e, Status{DPIR_ERR_HIP, "conv7 fused emission: a workgroup waited too long for the other workgroups of its image (results are invalid).  "
+                                            "Seen when three or more engines / processes share one GPU (two are fine, tools/concurrency_probe.py forwards "
+                                            "--engines N): run one engine per device, or set DPIR_FUSE_H1=0"});
     return fail(e, Status{DPIR_ERR_RANGE, std::string(e->precision == 2 ? "f16x1" : "f16x3") + " precision mode: " + std::to_string(n) +
                                           " activation lane(s) exceeded the f16 operand range (|v| > 65000 or NaN) and were clamped since the "
                                           "last forward / loop started -- results are invalid; rerun with precision f32 (engine_precision: f32)"});

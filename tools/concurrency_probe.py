@@ -54,21 +54,34 @@ def cmd_loops(args):
 
 
 def cmd_forwards(args):
-    x = np.random.default_rng(0).standard_normal((16, 3, H, H)).astype(np.float32)
+    """--engines N (default 2): N engines, 8 images each.  With the fused GroupNorm hop of conv7 (Conv6Emit) an (image, co-block) wait set is
+    up to 256 of the chip's 512 resident workgroups: two engines' sets fit side by side, three are not covered by that argument -- the
+    probe reports either bitwise equality or the engine's own "waited too long" error (never a hang: the wait is bounded)."""
+    n = args.engines
+    x = np.random.default_rng(0).standard_normal((8 * n, 3, H, H)).astype(np.float32)
     t = np.full(8, 500)
     for prec in args.precisions.split(","):
-        e0, e1 = mk(prec), mk(prec)
-        xa, xb = e0.to_device(x[:8]), e1.to_device(x[8:])
-        ra = e0.unet_forward(xa, t); e0.sync(); rb = e1.unet_forward(xb, t); e1.sync()
-        ra, rb = ra.numpy(), rb.numpy()
-        oa, ob = e0.empty(ra.shape), e1.empty(rb.shape)
-        worst = 0.0
-        for _ in range(20):
-            e0.unet_forward(xa, t, out=oa); e1.unet_forward(xb, t, out=ob)
-            e0.sync(); e1.sync()
-            worst = max(worst, np.abs(oa.numpy() - ra).max(), np.abs(ob.numpy() - rb).max())
-        print(f"[{prec}] concurrent forwards vs sequential: max|diff| {worst:.3e}", flush=True)
-        e0.close(); e1.close()
+        es = [mk(prec) for _ in range(n)]
+        xs = [e.to_device(x[8 * i:8 * i + 8]) for i, e in enumerate(es)]
+        refs = []
+        for e, xi in zip(es, xs):
+            r = e.unet_forward(xi, t); e.sync(); refs.append(r.numpy())
+        outs = [e.empty(refs[0].shape) for e in es]
+        worst, errors = 0.0, 0
+        rounds = 20 if n <= 2 else 6
+        for _ in range(rounds):
+            try:
+                for e, xi, o in zip(es, xs, outs): e.unet_forward(xi, t, out=o)
+                for e in es: e.sync()
+                worst = max([worst] + [float(np.abs(o.numpy() - r).max()) for o, r in zip(outs, refs)])
+            except diffpir_amd.EngineError as ex:
+                errors += 1
+                print(f"[{prec}] engine error under concurrency: {str(ex)[:160]}", flush=True)
+                for e in es:
+                    try: e.sync()
+                    except diffpir_amd.EngineError: pass
+        print(f"[{prec}] {n} engines, concurrent forwards vs sequential: max|diff| {worst:.3e}, rounds with an engine error {errors}/{rounds}", flush=True)
+        for e in es: e.close()
 
 
 def cmd_fft(args):
@@ -132,5 +145,6 @@ if __name__ == "__main__":
     ap.add_argument("--precisions", default="f16x3,f32")
     ap.add_argument("--cases", default="deblur:1:2,deblur:1:8,deblur:0:30,inpaint:1:30,deblur:1:30")
     ap.add_argument("--aggressor", default="conv6", choices=sorted(AGGRESSORS))
+    ap.add_argument("--engines", type=int, default=2, help="forwards: number of engines sharing the GPU")
     a = ap.parse_args()
     {"loops": cmd_loops, "forwards": cmd_forwards, "fft": cmd_fft, "victim": cmd_victim}[a.what](a)
