@@ -32,6 +32,23 @@ def klass(d, tag, pat, src):
             tot_b += b; tot_n += n
     return {"bytes_per_launch": round(tot_b / max(tot_n, 1)), "dispatches": tot_n, "kernels": rows, "source": src}
 
+def whole_forward(d, tag, forwards=3):
+    """All kernels of the profiled run (tools/prof_forward.py: `forwards` UNet forwards + 3 prox applies + one pre_calculate, the latter two
+    < 0.5 % of the bytes), per forward -- the figure the round-3 review summed by hand (49.7 GB at B = 16)."""
+    f, w = parse(os.path.join(d, f"{tag}_pmc_FETCH_SIZE.txt")), parse(os.path.join(d, f"{tag}_pmc_WRITE_SIZE.txt"))
+    fs = sum(v["FETCH_SIZE"][0] for v in f.values() if "FETCH_SIZE" in v)
+    ws = sum(v["WRITE_SIZE"][0] for v in w.values() if "WRITE_SIZE" in v)
+    by = {}
+    for name in f:
+        if name in w and "FETCH_SIZE" in f[name] and "WRITE_SIZE" in w[name]:
+            key = re.sub(r"<.*", "", re.sub(r"^void ", "", name)).replace("dpir::", "")
+            key = "act_split" if "act_split" in key else key
+            by[key] = by.get(key, 0.0) + (2 * f[name]["FETCH_SIZE"][0] + w[name]["WRITE_SIZE"][0]) * 1024.0 / forwards
+    top = dict(sorted(((k, round(v / 1e9, 2)) for k, v in by.items()), key=lambda kv: -kv[1])[:8])
+    return {"GB_per_forward": round((2 * fs + ws) * 1024.0 / forwards / 1e9, 2), "fetch_GB_raw": round(fs * 1024.0 / forwards / 1e9, 2),
+            "write_GB": round(ws * 1024.0 / forwards / 1e9, 2), "GB_per_forward_by_kernel_family": top}
+
+
 d = sys.argv[1]
 src = f"{d}/<case>_pmc_{{FETCH,WRITE}}_SIZE.txt: separate rocprofv3 --pmc passes over tools/prof_forward.py (tools/gpu_prof_round.sh), FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, KB -> bytes, launch-weighted over the kernels of the class"
 out = {
@@ -41,8 +58,11 @@ out = {
     "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
     "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
 }
+out["ffhq_B16_256_f16x3"]["whole_forward"] = whole_forward(d, "ffhq_f16x3")
+out["imagenet256_B32_256_f16x3"]["whole_forward"] = whole_forward(d, "in256_f16x3")
 for k in ("fftprox_sf1_B16_256", "fftprox_sf4_B32_256"):
     out[k]["note"] = "per-launch average over the three kernels of one apply AND the pre_calculate launches of the profiled run; bytes per apply = sum of the three apply kernels' rows"
 json.dump(out, open(os.path.join(os.path.dirname(d.rstrip('/')), "pmc_traffic.json"), "w"), indent=1)
+print("whole forward:", out["ffhq_B16_256_f16x3"]["whole_forward"], out["imagenet256_B32_256_f16x3"]["whole_forward"])
 for k, v in out.items():
     print(k, v["bytes_per_launch"], v["dispatches"], {n[:60]: (r["bytes_per_launch"], r["avg_us"], r["TBps"]) for n, r in v["kernels"].items()})
