@@ -582,10 +582,15 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, Pendi
     k.n_co_blocks = (a.Cout + 127) / 128;
     const int chunks = k.n_chunks_total;
     const int blocks = n_ptiles * k.n_co_blocks;
-    // split-K when the launch cannot give every CU its two workgroups (low-resolution layers); deterministic slabs
+    // split-K when the launch cannot give every CU its two workgroups (low-resolution layers); deterministic slabs.  The two constants
+    // are tuning knobs (A/B switches for tools/layer_roofline.py and tools/forward_time.py, read once): split launches with fewer
+    // than DPIR_SPLIT_BELOW workgroups so that about DPIR_SPLIT_TARGET result.  Every slice writes a full fp32 slab, so a lower target
+    // trades co-resident workgroups for slab traffic (per-shape figures: DESIGN.md section 6).
+    static const int split_below = getenv("DPIR_SPLIT_BELOW") ? atoi(getenv("DPIR_SPLIT_BELOW")) : 384;
+    static const int split_target = getenv("DPIR_SPLIT_TARGET") ? atoi(getenv("DPIR_SPLIT_TARGET")) : 512;
     int S = 1;
-    if (k.partial && blocks < 384) {
-        S = (512 + blocks - 1) / blocks;
+    if (k.partial && blocks < split_below) {
+        S = (split_target + blocks - 1) / blocks;
         if (S > chunks / 2) S = chunks / 2;
         if (S > 16) S = 16;
         if (S < 1) S = 1;

@@ -2,7 +2,8 @@
 is launched back to back on synthetic operands through the product's own dispatch (launch_conv6 -> conv7 / conv6, launch_conv5;
 dpir_debug_conv_bench of libdiffpir_dbg.so, f16x3 operand-split path), and its rate is held against the 833 TF/s-eq peak.  Back-to-back
 launches of ONE shape are the kernel's best case (warm L2, no neighbours); the sum over the forward's launch counts is printed next to
-the 3x3-class time the bench measures inside the network.  GPU box only.   usage: python tools/layer_roofline.py [B] [first N shapes]"""
+the 3x3-class time the bench measures inside the network.  GPU box only.  DPIR_SPLIT_TARGET / DPIR_SPLIT_BELOW (csrc/conv6.hip) change the
+split-K rule of the low-resolution shapes for an A/B.   usage: python tools/layer_roofline.py [B] [first N shapes]"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import diffpir_amd
