@@ -12,6 +12,8 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # DIFFPIR_LIB: developer override used to A/B kernel variants on one GPU box; the default is the in-tree build
 LIB_PATH = os.environ.get("DIFFPIR_LIB") or os.path.join(_HERE, "csrc", "libdiffpir_hip.so")
+ABI_VERSION = 2      # include/diffpir_engine.h DPIR_ABI_VERSION: bumped whenever a public struct layout changes
+
 
 
 class UNetDesc(C.Structure):
@@ -140,6 +142,7 @@ def load_debug():
         raise EngineLibraryError(f"{DEBUG_LIB_PATH} not found: `make -C diffpir_amd/csrc` builds it next to the product library")
     d = C.CDLL(DEBUG_LIB_PATH)
     d.dpir_debug_conv_bench.argtypes = [C.c_void_p] + [C.c_int] * 10 + [C.POINTER(C.c_double)]
+    d.dpir_debug_conv7_emit_supported.argtypes = [C.c_void_p] + [C.c_int] * 4 + [C.POINTER(C.c_int)]
     d.dpir_debug_victim.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_longlong, C.c_int, C.POINTER(C.c_ulonglong)]
     d.dpir_debug_victim_alu.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_ulonglong)]
     for fn in (d.dpir_debug_victim_fft_pk, d.dpir_debug_victim_fft_nopk):
@@ -183,7 +186,7 @@ def load():
             raise EngineLibraryError(f"{LIB_PATH} does not export {name}") from ex
         fn.restype = res
         fn.argtypes = args
-    if lib.dpir_version() != 1:
+    if lib.dpir_version() != ABI_VERSION:
         raise EngineLibraryError("ABI version mismatch")
     _lib = lib
     return lib

@@ -196,6 +196,19 @@ constexpr int kConv5EmitMaxC = 384;            // channels of the GroupNorm tabl
 bool conv5_supported(int B, int Cout, int H, int W, bool has_prm = false);
 Status launch_conv5(hipStream_t s, const Conv5Args& a);
 float pack_weights_f16x3_1x1(const float* w_oi, int cout, int cin, std::vector<uint16_t>& out);
+// conv8.hip: GroupNorm affine + SiLU + f16 split + 3x3 convolution to <= 16 output channels in one kernel (the network's output layer)
+struct Conv8Args {
+    const float* x = nullptr;                  // [B][C][H][W] fp32, single source, same resolution
+    const float4* prm = nullptr;               // [B][C] {mean, scale, shift, silu flag} (launch_gn_prm)
+    const void* w = nullptr; float w_scale = 1.f;    // pack_weights_conv8 layout
+    const float* bias = nullptr; float* out = nullptr;
+    int B = 0, C = 0, Cout = 0, H = 0, W = 0;
+    unsigned long long* range_ctr = nullptr;
+    bool x1 = false;                           // single-product mode (f16x1)
+};
+bool conv8_supported(int B, int C, int Cout, int H, int W);
+Status launch_conv8(hipStream_t s, const Conv8Args& a);
+float pack_weights_conv8(const float* w_oihw, int cout, int cin, std::vector<uint16_t>& out);
 // part[n*C+c] = fp64 {sum, sum of squares} of one channel plane of the (virtual-concat) input
 Status launch_gn_stats(hipStream_t s, CatSrc src, int B, int HW, double2* part);
 // statistics of one tensor of a virtual concat: conv6 epilogue slots [B][c][nslots] (float2) or, when slots == null,

@@ -524,8 +524,11 @@ bool conv6_supported(int H, int W) { return conv6_geo(H, W) >= 0; }
 // together with room to spare (the chip holds 512)
 bool conv7_emit_supported(int B, int Cout, int H, int W) {
     if (conv6_geo(H, W) != 0 || (W & 31) || (H & 7) || (Cout & 127)) return false;
+    // the emission folds per-group sums inside one wave: channels per group (Cout / 32) must divide the 64 channels a wave owns, i.e. Cout in
+    // {128, 256, 512, 1024, 2048}; 384 / 640 / 768 / 896 (channel_mult x3, x5, x6, x7) have groups that straddle waves -> unfused path
+    if (64 % (Cout / 32) != 0) return false;
     const int tiles = (W / 32) * (H / 8);
-    return tiles <= 256 && tiles * (Cout / 128) * B >= 384;
+    return tiles <= conv7_emit_capacity() / 2 && tiles * (Cout / 128) * B >= 384;
 }
 
 // statistics slots per (image, channel) plane written by the epilogue when no split-K is used

@@ -37,5 +37,6 @@ struct Conv6K {
 // conv7.hip: every case of launch_conv6 (all three geometries, split-K slabs, f16x1, dgrad scale) with the workgroup tile cut as
 // 64 co x 128 px per wave; blocks = pixel tiles x co-blocks x ksplit
 Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks, bool x1);
+int conv7_emit_capacity();     // resident EMIT workgroups on this device (CUs x occupancy)
 
 }  // namespace dpir

@@ -546,6 +546,22 @@ static Status launch7(hipStream_t s, const Conv6K& k, int blocks) {
     return Status{};
 }
 
+// Workgroups of the EMIT kernel the device holds at once: CUs x resident workgroups per CU (occupancy API, capped by the kernel's launch
+// bound of two).  The fused hop's waiting set -- the workgroups of one (image, co-block) -- must fit with room to spare
+// (conv7_emit_supported: at most HALF of this), instead of the constants 256 / 512 of an MI355X being assumed.
+int conv7_emit_capacity() {
+    static int cap = -1;
+    if (cap >= 0) return cap;
+    int dev = 0, cus = 0, occ = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return cap = 0;
+    using G = Geo7<0>;
+    constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
+    constexpr size_t LDS = (size_t)4 * ((2 * PATCH + 63) / 64) * 1024;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv7_mfma_kernel<0, false, false, true>, 256, LDS) != hipSuccess || occ < 1) occ = 1;
+    if (occ > 2) occ = 2;
+    return cap = cus * occ;
+}
+
 // k as launch_conv6 fills it (geometry from H, W as conv6_geo); blocks = pixel tiles x co-blocks x ksplit
 Status launch_conv7(hipStream_t s, const Conv6K& k, int blocks, bool x1) {
     if ((k.W & 3) || k.W < 8 || k.H < 8) return invalid("conv7: shape not tiled");

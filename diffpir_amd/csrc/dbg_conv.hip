@@ -223,4 +223,11 @@ int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int 
     return DPIR_OK;
 }
 
+int dpir_debug_conv7_emit_supported(dpir_engine* e, int B, int Cout, int H, int W, int* capacity_out) {
+    if (!e) return 0;
+    (void)hipSetDevice(e->device);
+    if (capacity_out) *capacity_out = conv7_emit_capacity();
+    return conv7_emit_supported(B, Cout, H, W) ? 1 : 0;
+}
+
 }  // extern "C"

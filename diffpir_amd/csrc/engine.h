@@ -1,5 +1,6 @@
 // Engine state: device arena, UNet plan + weights, workspaces.
 #pragma once
+#include <functional>
 #include "common.h"
 #include "elem.h"
 
@@ -29,6 +30,7 @@ struct Workspace {
 struct ConvW { float* w = nullptr; float* bias = nullptr; int cin = 0, cout = 0, coutp = 0, ks = 3;
                void* w16 = nullptr; float w16_scale = 1.f;      // operand-split f16 copy (precision modes 1, 2): conv6 layout for 3x3, conv5 layout for 1x1
                float* wT = nullptr; int coutpT = 0;             // grad mode: the dgrad operand [coutP16][taps flipped][cinP64] (unet_bwd.hip)
+               void* w8 = nullptr; float w8_scale = 1.f;        // 3x3 with cout <= 16 and cin % 32 == 0: conv8 layout (fused GroupNorm/SiLU/split prologue)
                void* w16T = nullptr; float w16T_scale = 1.f; }; // grad mode in the f16 precisions: the same operand in conv6 / conv5 split layout
 struct GnW { float* gamma = nullptr; float* beta = nullptr; int c = 0; };
 struct ResW {
@@ -66,6 +68,7 @@ struct TapeAttn { int idx; const float* in; int H, W; float* qkv; float* att; fl
 struct TapeNode { int kind; int idx; };      // 1: res[idx], 2: attn[idx]
 struct Tape {
     bool valid = false;
+    unsigned long long serial = 0;      // which forward recorded it (dpir_engine::fwd_serial at that time)
     int B = 0, H = 0, W = 0;
     float* conv_in_out = nullptr;
     std::vector<TapeNode> nodes; std::vector<TapeRes> res; std::vector<TapeAttn> attn;
@@ -109,6 +112,7 @@ struct dpir_engine {
     dpir::Tape tape;
     // the last p_sample (dpir_p_sample / the DPS loop): what dpir_grad_and_value(x, x_hat = that call's pred_xstart) differentiates through
     float ps_c1 = 0.f, ps_c2 = 0.f; int ps_B = 0, ps_H = 0, ps_W = 0; const float* ps_x0 = nullptr;
+    unsigned long long fwd_serial = 0, ps_serial = 0;   // forwards so far; the forward p_sample ran (any later forward rebuilds the tape: ps_serial goes stale)
     // Captured restoration steps.  A graph depends only on what is baked into its kernel arguments: the shape / task /
     // mode fields below and the workspace generation; per-batch pointers, seed and image offset live in a device block
     // (dpir::LoopDev), so every batch of a test set replays the same graph.  Entries are compared field by field on a
@@ -129,6 +133,12 @@ struct dpir_engine {
         graphs.clear();
     }
     unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
+    // conv7's fused hop (Conv6Emit) is an inter-workgroup wait; when it times out (the GPU is shared with other engines / processes) the
+    // engine does not fail: it switches the hop off for its lifetime and re-runs what the time-out invalidated -- the restoration loop
+    // (dpir_run_loop) or the ONE eager forward issued since the last synchronisation (replay_last); see dpir_check_range
+    bool fuse_h1_off = false;
+    int fwd_since_sync = 0;
+    std::function<int()> replay_last;
     void* comm = nullptr; int comm_world = 1, comm_rank = 0;     // RCCL communicator (comm.cpp), or null
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);

@@ -117,6 +117,15 @@ Status load_conv(dpir_engine* e, const WeightMap& wm, const std::string& p, int 
         e->net.allocs.push_back(p);
         DPIR_HIP(hipMemcpy(p, w16.data(), w16.size() * 2, hipMemcpyHostToDevice));
         out->w16 = p;
+        if (ks == 3 && !one_d && cout <= 16 && cin % 32 == 0) {
+            std::vector<uint16_t> w8;
+            out->w8_scale = pack_weights_conv8(w, cout, cin, w8);
+            void* p8 = nullptr;
+            if (hipMalloc(&p8, w8.size() * 2) != hipSuccess) return Status{DPIR_ERR_NOMEM, "hipMalloc for the conv8 weights failed"};
+            e->net.allocs.push_back(p8);
+            DPIR_HIP(hipMemcpy(p8, w8.data(), w8.size() * 2, hipMemcpyHostToDevice));
+            out->w8 = p8;
+        }
     }
     return Status{};
 }
@@ -410,6 +419,18 @@ struct Fwd {
         const bool use5 = cw.w16 && cw.ks == 1 && mode == 0 && (!res || res_mode == 0) && conv5_supported(B, cw.cout, Ho, Wo, prm != nullptr) &&
                           !(prm && in.C() % 16);   // no slab buffer
         if (pending.partial && (is_pending(in.a) || is_pending(in.b) || is_pending(res) || !use5)) DPIR_TRY(resolve());
+        // the output layer (128 -> 6): GroupNorm / SiLU / split happen in the convolution's own LDS fill (conv8.hip); grad mode keeps the
+        // planes route (the backward pass reads act#s16)
+        static const bool use_conv8 = !(getenv("DPIR_CONV8") && atoi(getenv("DPIR_CONV8")) == 0);
+        if (use_conv8 && cw.w8 && prm && !grad && !emit && !res && mode == 0 && !in.b && in.H == Ho && in.W == Wo &&
+            conv8_supported(B, in.C(), cw.cout, Ho, Wo)) {
+            Conv8Args a8;
+            a8.x = in.a; a8.prm = prm; a8.w = cw.w8; a8.w_scale = cw.w8_scale; a8.bias = cw.bias; a8.out = out;
+            a8.B = B; a8.C = in.C(); a8.Cout = cw.cout; a8.H = Ho; a8.W = Wo; a8.range_ctr = e->range_ctr; a8.x1 = x1;
+            fused.erase(out);
+            ProfScope ps(&e->prof, PC_CONV3);
+            return launch_conv8(s, a8);
+        }
         if (cw.w16 && cw.ks == 3 && conv6_supported(Ho, Wo)) {
             // operand-split f16 path: one elementwise pre-pass (GroupNorm/FiLM/SiLU/resample/concat/split),
             // then conv6 (pure LDS-DMA + MFMA, two workgroups per CU); GroupNorm statistics of the output come out of its
@@ -695,13 +716,14 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
         f.fuse_small = fuse_env;
         f.emit_skip = emit_env;
         static const bool fuse_h1_env = !(getenv("DPIR_FUSE_H1") && atoi(getenv("DPIR_FUSE_H1")) == 0);
-        f.fuse_h1 = fuse_h1_env && !f.grad && e->precision != 0;
+        f.fuse_h1 = fuse_h1_env && !e->fuse_h1_off && !f.grad && e->precision != 0;
         if (f.fuse_h1) {       // accumulators + arrival counters of the fused conv1 -> conv2 hops: one arena, zeroed once per forward
             f.fuse_cap = (size_t)B * 4096;         // 8-byte words: room for ~60 fused hops of (64 + Cout / 128) words per image
             DPIR_TRY(ws.getT("fuse#arena", f.fuse_cap, &f.fuse_arena));
             DPIR_HIP(hipMemsetAsync(f.fuse_arena, 0, f.fuse_cap * sizeof(long long), s));
         }
-        if (f.grad) { e->tape.clear(); e->tape.B = B; e->tape.H = H; e->tape.W = W; }
+        ++e->fwd_serial;
+        if (f.grad) { e->tape.clear(); e->tape.serial = e->fwd_serial; e->tape.B = B; e->tape.H = H; e->tape.W = W; }
     }
     if (e->collect_taps) e->taps.clear();
 

@@ -95,11 +95,52 @@ def load_images(config, n_synth):
     return np.ascontiguousarray((f * 255.0).round().astype(np.uint8).transpose(0, 2, 3, 1)), [f"synth_{i:04d}.png" for i in range(n)]
 
 
+_MAT_CACHE = {}
+
+
+def load_reference_kernels(config, name):
+    """kernels/<name>.mat of the reference tree (main_ddpir.py:54, 71: hdf5storage.loadmat(...)['kernels']) -> object array [1, n] of 2-D
+    float arrays, or None when the file is not under <cwd>/kernels.  The two v5 files are read with scipy; Levin09.mat is v7.3 (HDF5):
+    h5py if importable, else a `<name>.npz` beside it (tools/convert_mat_v73.py writes it under an interpreter that has h5py)."""
+    path = os.path.join(config.get("cwd", "") or "", "kernels", name + ".mat")
+    if path in _MAT_CACHE:
+        return _MAT_CACHE[path]
+    cell = None
+    if os.path.exists(path):
+        try:
+            import scipy.io
+            cell = scipy.io.loadmat(path)["kernels"]
+        except NotImplementedError:
+            try:
+                import h5py
+                with h5py.File(path, "r") as f:
+                    refs = f["kernels"]
+                    ks = [np.array(f[refs[i, 0]]).T for i in range(refs.shape[0])]     # MATLAB is column-major: h5py sees the transpose
+            except ImportError:
+                side = os.path.splitext(path)[0] + ".npz"
+                if not os.path.exists(side):
+                    raise RuntimeError(f"{path} is a MATLAB v7.3 (HDF5) file and h5py is not importable here: convert it once with "
+                                       f"`<python with h5py> tools/convert_mat_v73.py {path}` (writes {side})")
+                z = np.load(side)
+                ks = [z[f"k{i}"] for i in range(len(z.files))]
+            cell = np.empty((1, len(ks)), dtype=object)
+            for i, kk in enumerate(ks):
+                cell[0, i] = kk
+    _MAT_CACHE[path] = cell
+    return cell
+
+
 def make_operators(config, n, idx0, H, W):
     """Per-image PSFs / masks of CustomDataset.__getitem__ (main_ddpir.py:52-110): a few hundred scalar operations per image
     under the numpy RNG, kept on the host so that they stay bit-identical to the reference's.  Returns (k, mask) numpy or None."""
     k = mask = None
-    if config.task == "deblur":
+    if config.task == "deblur" and not config.get("use_DIY_kernel", True):
+        # main_ddpir.py:69-72: k_index = 0 of kernels/Levin09.mat, float32, the same PSF for every image
+        cell = load_reference_kernels(config, "Levin09")
+        if cell is None:
+            raise FileNotFoundError("use_DIY_kernel: false needs kernels/Levin09.mat under `cwd` (main_ddpir.py:71); it is not there")
+        k = np.broadcast_to(cell[0, 0].astype(np.float32), (n, 1) + cell[0, 0].shape).copy()
+    elif config.task == "deblur":
         ks = []
         for b in range(n):
             np.random.seed(seed=(idx0 + b) * 10)                            # main_ddpir.py:59
@@ -109,7 +150,19 @@ def make_operators(config, n, idx0, H, W):
                 ks.append(synth.motion_psf(config.kernel_size, seed=idx0 + b))
         k = np.stack(ks)[:, None].astype(np.float32)
     elif config.task == "sr":
-        k = np.broadcast_to(synth.bicubic_psf_x4(), (n, 1, 25, 25)).copy()
+        # main_ddpir.py:53-56: kernels_bicubicx234.mat[0, sf - 2] (index 2 for sf >= 5)
+        cell = load_reference_kernels(config, "kernels_bicubicx234")
+        if cell is not None:
+            kk = cell[0, config.sf - 2 if config.sf < 5 else 2].astype(np.float64).astype(np.float32)
+        else:
+            if config.sf != 4:
+                raise FileNotFoundError(f"task sr, sf = {config.sf}: kernels/kernels_bicubicx234.mat is not under `cwd` and the built-in stand-in exists for sf = 4 only")
+            if not _MAT_CACHE.get("warned"):
+                log.warning("kernels/kernels_bicubicx234.mat not found under cwd=%r: using the ANALYTIC x4 bicubic PSF stand-in (differs from the "
+                            "reference's file by up to 1.9e-3 per tap, 3 %% of the peak) -- results will not match a reference run", config.get("cwd", ""))
+                _MAT_CACHE["warned"] = True
+            kk = synth.bicubic_psf_x4()
+        k = np.broadcast_to(kk, (n, 1) + kk.shape).copy()
     else:
         gen = mask_generator(config.mask_type, config.mask_len_range, config.mask_prob_range)
         mask = np.concatenate([gen((1, 3, H, W)) for _ in range(n)], 0)
@@ -170,6 +223,10 @@ def main(argv=None):
     results = []
     cache = {}
     import torch
+    # every batch's sharding is checked BEFORE any work starts (a ragged last batch smaller than the world used to raise after all earlier
+    # batches had been computed, losing the run)
+    for i0 in range(0, len(imgs), config.batch_size):
+        ddist.check_dps_sharding(eng, loop_config(config, *sweeps(config)[0]), min(config.batch_size, len(imgs) - i0), world)
     for si, (lambda_, zeta) in enumerate(sweeps(config)):
         if args.max_sweeps and si >= args.max_sweeps:
             break

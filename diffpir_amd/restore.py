@@ -114,7 +114,8 @@ def _steps(cfg: LoopConfig):
                 raise NotImplementedError("skip_noise_model_t with iter_num > T - noise_model_t selects the reference's pred_x_prev "
                                           "fallback (main_ddpir.py:407-413), which is not on the accelerated path")
     return build_steps(iter_num=cfg.iter_num, sigma=cfg.sigma, lambda_=cfg.lambda_, zeta=cfg.zeta, eta=cfg.eta,
-                       skip_type=cfg.skip_type, T=T, beta_start=cfg.beta_start, beta_end=cfg.beta_end, t_start=t_start)
+                       skip_type=cfg.skip_type, T=T, beta_start=cfg.beta_start, beta_end=cfg.beta_end, t_start=t_start,
+                       generate_mode=cfg.generate_mode, model_output_type=cfg.model_output_type)
 
 
 def draw_host_noise(noise_fn: Callable, steps, shape, need_n1: bool, repaint: bool = False):

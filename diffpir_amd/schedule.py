@@ -105,10 +105,12 @@ def make_seq(T: int, iter_num: int, skip_type: str = "quad") -> List[int]:
 
 def build_steps(*, iter_num: int, sigma: float, lambda_: float, zeta: float, eta: float = 0.0,
                 skip_type: str = "quad", T: int = 1000, beta_start=0.0001, beta_end=0.02,
-                t_start: int = None):
+                t_start: int = None, generate_mode: str = "DiffPIR", model_output_type: str = "pred_xstart"):
     """Returns (DriverTables, list of python dicts, ctypes Step array) for one (lambda, zeta) setting.
 
-    sigma = max(0.001, noise_level_img/255) (main_ddpir.py:141)."""
+    sigma = max(0.001, noise_level_img/255) (main_ddpir.py:141).  generate_mode / model_output_type select the sigma_k table the
+    rhos are built from (main_ddpir.py:279-283): sigma_bar_t only for (pred_xstart, DiffPIR), sqrt(beta_t / alpha_t) otherwise --
+    which is what generate_mode DPS_yt divides its step by (:443)."""
     dt = DriverTables.make(beta_start, beta_end, T)
     dtab = DiffusionTables.make(T)
     if t_start is None:
@@ -118,7 +120,11 @@ def build_steps(*, iter_num: int, sigma: float, lambda_: float, zeta: float, eta
     # torch 0-dim float32 tensors like main_ddpir.py:277-286 (python-float / tensor = reciprocal * scalar)
     import torch
     t_s1m, t_sa = torch.from_numpy(dt.sqrt_1m_ac), torch.from_numpy(dt.sqrt_ac)
-    sigma_ks = t_s1m / t_sa
+    if model_output_type == "pred_xstart" and generate_mode == "DiffPIR":
+        sigma_ks = t_s1m / t_sa                           # main_ddpir.py:279-280
+    else:
+        t_betas = torch.from_numpy(dt.betas)
+        sigma_ks = torch.sqrt(t_betas / (1.0 - t_betas))  # main_ddpir.py:282-283 (alphas = 1.0 - betas, :186)
     rhos = (lambda_ * (sigma ** 2) / (sigma_ks ** 2)).float().numpy()
     t_list = [find_nearest(dt.reduced, dt.reduced[T - 1 - s]) for s in seq]
     steps = []

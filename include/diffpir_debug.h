@@ -28,6 +28,9 @@ int dpir_debug_victim_fft_nopk(dpir_engine* e, int blocks, int iters_in_kernel, 
  * difference, *ms6_out / *ms7_out the average launch times over `iters` back-to-back launches. */
 int dpir_debug_conv7_check(dpir_engine* e, int B, int Cin, int Cout, int H, int W, int res_mode, int x1, int split, int scaled, int iters,
                            double* ms6_out, double* ms7_out, unsigned long long* mismatches_out, float* maxdiff_out, int* ksplit_out);
+/* 1 when a 3x3 launch of this shape may take conv7's fused GroupNorm hop (Conv6Emit), 0 when the dispatch falls back to the unfused path;
+ * *capacity_out = resident EMIT workgroups of the device (CUs x occupancy) the waiting-set limit is derived from. */
+int dpir_debug_conv7_emit_supported(dpir_engine* e, int B, int Cout, int H, int W, int* capacity_out);
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define DPIR_ABI_VERSION 1
+#define DPIR_ABI_VERSION 2   /* 2 (round 5): dpir_dps_coef grew to 24 bytes and dpir_loop_desc gained ddim_sample in round 4 without a bump; bumped with every public struct layout change from here on */
 
 typedef enum dpir_status {
     DPIR_OK = 0,

@@ -63,6 +63,16 @@ class DiffusionTables:
         self.alphas_cumprod_prev = ac_prev
 
 
+def loader_strides(t):
+    """The same values with the strides the reference's DataLoader path gives a batch: CustomDataset yields NHWC numpy arrays and
+    util.single2tensor4_batch (utils_image.py:255-256) / main_ddpir.py:295 only `.permute(0, 3, 1, 2)` them, so `y`, `mask` and hence
+    `x` enter the loop as NCHW VIEWS of NHWC memory (channels-last).  ATen's CPU convolution / interpolation kernels are chosen by
+    memory format and round differently in the last bits (measured: up to 8e-5 after a 5-step loop on the tiny network, 0.0 once the
+    strides match -- profiles/r05/oracle_glue_equivalence.log), so a bit-level comparison with a reference-executed fixture has to
+    start from the same layout."""
+    return None if t is None else t.permute(0, 2, 3, 1).contiguous().permute(0, 3, 1, 2)
+
+
 def find_nearest(array, value) -> int:
     """utils_model.py:202-205."""
     array = np.asarray(array)
@@ -122,7 +132,10 @@ def step_tables(cfg: LoopConfig):
     T = cfg.T
     # main_ddpir.py:274-286
     sigmas = [dt.reduced[T - 1 - i] for i in range(T)]
-    sigma_ks = [dt.sqrt_1m_ac[i] / dt.sqrt_ac[i] for i in range(T)]
+    if cfg.generate_mode == "DiffPIR":                      # main_ddpir.py:279-283 (model_out_type is 'pred_xstart' throughout the oracle)
+        sigma_ks = [dt.sqrt_1m_ac[i] / dt.sqrt_ac[i] for i in range(T)]
+    else:
+        sigma_ks = [torch.sqrt(dt.betas[i] / dt.alphas[i]) for i in range(T)]
     rhos = [cfg.lambda_ * (cfg.sigma ** 2) / (sigma_ks[i] ** 2) for i in range(T)]
     rhos = torch.tensor(rhos)
     sigmas = torch.tensor(sigmas)
@@ -342,7 +355,7 @@ def restore_dps_y0(sd, hp, cfg: LoopConfig, y, noise_fn: Callable, y_label=None,
         raise ValueError("DPS_y0 is runnable in the reference for task 'sr' only")
     dt, steps = step_tables(cfg)
     dtab = DiffusionTables(cfg.T)
-    y = y.float()
+    y = loader_strides(y.float())                   # the memory layout the reference's loader gives (see loader_strides)
     t_start = cfg.t_start(dt)
     H, W = y.shape[2] * cfg.sf, y.shape[3] * cfg.sf
     x = init_x(cfg, y, None, dt, noise_fn(torch.empty(y.shape[0], 3, H, W)), t_start)
@@ -395,9 +408,9 @@ def restore(sd, hp, cfg: LoopConfig, y, k=None, mask=None, noise_fn: Callable = 
     Returns x_0 in [0,1] (un-clamped, main_ddpir.py:470)."""
     dt, steps = step_tables(cfg)
     dtab = DiffusionTables(cfg.T)
-    y = y.float()
+    y = loader_strides(y.float())                   # the memory layout the reference's loader gives (see loader_strides)
     if cfg.task == "inpaint":
-        mask = mask.float()
+        mask = loader_strides(mask.float())
     t_start = cfg.t_start(dt)
     x = init_x(cfg, y, mask, dt, noise_fn(torch.empty(y.shape[0], 3, y.shape[2] * cfg.sf, y.shape[3] * cfg.sf)), t_start)
     pre = None

@@ -16,11 +16,11 @@ import sys
 import numpy as np
 import torch
 
-from . import ref_import, live_reference as live
+from . import ref_import, ref_exec
 from . import unet_oracle as uo
 from . import diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def seeded_noise_fn(seed):
@@ -71,7 +71,15 @@ def main():
         t_is = [int(ns.utils_model.find_nearest(red, sigmas[s].cpu().numpy())) for s in seq]
         sched[name + "_t"] = np.array(t_is, dtype=np.int64)
         sched[name + "_tau"] = np.array([float(rhos[t].float()) for t in t_is], dtype=np.float32)
-    _, diffusion = live.build_unet(uo.tiny_hp(), uo.synth_state_dict(uo.tiny_hp(), 0))
+    # the same tables out of the reference's OWN statements (oracle/ref_exec.py: test_rho executed with a recording stand-in for the
+    # network and for data_solution): every t_i it visits and every tau it hands to the prox
+    for name, task, over in (("deblur100", "deblur", dict(iter_num=100)), ("sr100", "sr", dict(iter_num=100, zeta=0.25))):
+        ts, taus = ref_exec.reference_step_trace(ref_exec.yaml_for(task, **over), (1, 3, 8, 8), sweep=True)
+        n = len(sched[name + "_t"])
+        i = 4 if task == "sr" else 0            # the sr sweep runs lambda = 2 .. 12 (main_ddpir.py:556): lambda 6 is its fifth pass
+        assert np.array_equal(ts[i * n:(i + 1) * n], sched[name + "_t"]) and np.array_equal(taus[i * (n - 1):(i + 1) * (n - 1)], sched[name + "_tau"][:n - 1]), name
+        print("schedule", name, ": executed test_rho (incl. the reference's lambda/zeta sweep) visits the same t_i / tau")
+    _, diffusion = ref_exec.build_unet(uo.tiny_hp(), uo.synth_state_dict(uo.tiny_hp(), 0))
     sched["sqrt_recip_ac"] = diffusion.sqrt_recip_alphas_cumprod
     sched["sqrt_recipm1_ac"] = diffusion.sqrt_recipm1_alphas_cumprod
     sched["drv_sqrt_ac"] = s_ac.numpy()
@@ -83,7 +91,7 @@ def main():
                                 ("tinycc", uo.tiny_hp(class_cond=True), 32, 2, [3, 7]),
                                 ("ffhq", uo.ffhq_hp(), 32, 1, None)):
         sd = uo.synth_state_dict(hp, 0)
-        model, _ = live.build_unet(hp, sd)
+        model, _ = ref_exec.build_unet(hp, sd)
         g = torch.Generator().manual_seed(11)
         x = torch.randn((B, 3, hw, hw), generator=g)
         t = torch.tensor([999, 37][:B])
@@ -149,7 +157,7 @@ def main():
     # ---------------------------------------------------------------- 4. whole loop, tiny UNet
     hp = uo.tiny_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     gt = smooth_images(2, 32, 32, 9)
     loops = dict(gt=gt)
     # deblur
@@ -159,10 +167,10 @@ def main():
     kt = torch.from_numpy(np.stack([kg, kg]))[:, None]
     cfg = do.LoopConfig("deblur", 6, 12.75 / 255, 7.0, 0.3)
     loops["deblur_y"], loops["deblur_k"] = yb, kt.numpy()
-    loops["deblur_out"] = live.restore_live(model, diffusion, cfg, torch.from_numpy(yb), k=kt, noise_fn=seeded_noise_fn(42)).numpy()
+    loops["deblur_out"] = ref_exec.restore_ref(model, diffusion, cfg, torch.from_numpy(yb), k=kt, noise_fn=seeded_noise_fn(42)).numpy()
     # deblur with eta != 0 (exercises the n1 term)
     cfg = do.LoopConfig("deblur", 5, 12.75 / 255, 7.0, 0.3, eta=0.7)
-    loops["deblur_eta_out"] = live.restore_live(model, diffusion, cfg, torch.from_numpy(yb), k=kt, noise_fn=seeded_noise_fn(43)).numpy()
+    loops["deblur_eta_out"] = ref_exec.restore_ref(model, diffusion, cfg, torch.from_numpy(yb), k=kt, noise_fn=seeded_noise_fn(43)).numpy()
     # inpaint (box mask scaled to 32x32)
     m = np.ones((2, 3, 32, 32), np.float32)
     m[0, :, 8:24, 6:22] = 0
@@ -170,7 +178,7 @@ def main():
     yi = (gt * m).astype(np.float32)
     cfg = do.LoopConfig("inpaint", 6, 0.0, 1.0, 1.0)
     loops["inpaint_y"], loops["inpaint_mask"] = yi, m.astype(np.uint8)
-    loops["inpaint_out"] = live.restore_live(model, diffusion, cfg, torch.from_numpy(yi), mask=torch.from_numpy(m), noise_fn=seeded_noise_fn(44)).numpy()
+    loops["inpaint_out"] = ref_exec.restore_ref(model, diffusion, cfg, torch.from_numpy(yi), mask=torch.from_numpy(m), noise_fn=seeded_noise_fn(44)).numpy()
     # sr x4, blur mode (bicubic PSF) and cubic mode (IBP)
     gt64 = smooth_images(2, 64, 64, 10)
     ylr = ns.utils_resizer.Resizer((2, 3, 64, 64), 0.25)(torch.from_numpy(gt64))
@@ -178,9 +186,9 @@ def main():
     k4 = torch.from_numpy(np.stack([k_bic4, k_bic4]))[:, None]
     loops["sr_gt"], loops["sr_y"] = gt64, ylr.numpy()
     cfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4)
-    loops["sr_blur_out"] = live.restore_live(model, diffusion, cfg, ylr, k=k4, noise_fn=seeded_noise_fn(45)).numpy()
+    loops["sr_blur_out"] = ref_exec.restore_ref(model, diffusion, cfg, ylr, k=k4, noise_fn=seeded_noise_fn(45)).numpy()
     cfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", inIter=2, gamma=0.5)
-    loops["sr_cubic_out"] = live.restore_live(model, diffusion, cfg, ylr, k=k4, noise_fn=seeded_noise_fn(46)).numpy()
+    loops["sr_cubic_out"] = ref_exec.restore_ref(model, diffusion, cfg, ylr, k=k4, noise_fn=seeded_noise_fn(46)).numpy()
     np.savez_compressed(os.path.join(OUT, "loops.npz"), **loops)
     for f in sorted(os.listdir(OUT)):
         print(f, os.path.getsize(os.path.join(OUT, f)))

@@ -1,4 +1,4 @@
-"""Golden vectors for the gradient-based mode from the LIVE reference:
+"""Golden vectors for the gradient-based mode from the reference's own test_rho (oracle/ref_exec.py) and functions:
 
   * `post_*`       : GaussianDiffusion's posterior / learned-range tables (gaussian_diffusion.py:153-167) that p_sample reads;
   * `vjp_tiny_*`, `vjp_ffhq64_*` : torch.autograd.grad of <UNetModel(x, t), g> w.r.t. x through the reference network (tiny topology at
@@ -14,9 +14,9 @@ import os
 import numpy as np
 import torch
 
-from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+from . import ref_exec, unet_oracle as uo, diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def seeded_noise_fn(seed):
@@ -26,7 +26,7 @@ def seeded_noise_fn(seed):
 
 def vjp_case(out, tag, hp, B, size, seed):
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd, frozen=False)
+    model, diffusion = ref_exec.build_unet(hp, sd, frozen=False)
     g = torch.Generator().manual_seed(seed)
     x = torch.randn((B, 3, size, size), generator=g)
     gout = torch.randn((B, 6, size, size), generator=g)
@@ -52,20 +52,22 @@ def main():
     cfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
     y, k = torch.from_numpy(case["y"]), torch.from_numpy(case["k"])
     tr, tro = [], []
-    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(81), trace=tr).numpy()
+    ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(81), trace=tr).numpy()
     ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(81), trace=tro).numpy()
-    ng = [v for n, _, v in tr if n == "norm_grad"][0].numpy()
+    ng = [v for n, v in tr if n == "norm_grad"][0].numpy()
     out.update(dps_y=case["y"], dps_gt=case["gt"], dps_out=ref, dps_seed=np.array(81), dps_nfe=np.array(5), dps_norm_grad0=ng)
     print("DPS_y0 5-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "| first norm_grad max", float(np.abs(ng).max()), flush=True)
-    # DPS_yt (main_ddpir.py:439-445; its step is 0.35 norm sigma_bar_t^2 / sigma^2 whatever lambda is, so it is only tame from a low
-    # t_start) and the first-order data step of the DiffPIR loop (sub_1_analytic: false, :420-430)
-    cfg = do.LoopConfig("sr", 10, 12.75 / 255, 600.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
-    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(82)).numpy()
+    # DPS_yt (main_ddpir.py:439-445) at the reference's own settings: lambda as configs/sisr.yaml's sweep sets it, noise_init_img 'max'.
+    # Its rhos are built from sigma_k = sqrt(beta_t / alpha_t) (main_ddpir.py:282-283: generate_mode != 'DiffPIR'), NOT from sigma_bar_t:
+    # rounds 1-4 had lost that branch in the hand-copied glue (and tamed the resulting blow-up with lambda = 600 / noise_init_img = 100).
+    cfg = do.LoopConfig("sr", 10, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt")
+    ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(82)).numpy()
     ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(82)).numpy()
-    out.update(dpsyt_out=ref, dpsyt_seed=np.array(82))
+    tabs = ref_exec.reference_tables(ref_exec.yaml_for("sr", iter_num=10, lambda_=6.0, zeta=0.25, generate_mode="DPS_yt", sr_mode="cubic"))
+    out.update(dpsyt_out=ref, dpsyt_seed=np.array(82), dpsyt_rhos=tabs["rhos"], dpsyt_lambda=np.array(6.0), dpsyt_nfe=np.array(10))
     print("DPS_yt loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()), flush=True)
     cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6.0e5, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
-    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
+    ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
     ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(83)).numpy()
     out.update(fo_out=ref, fo_seed=np.array(83))
     print("first-order loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(ref.min()), float(ref.max()), flush=True)

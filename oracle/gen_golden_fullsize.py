@@ -14,9 +14,9 @@ import os
 import numpy as np
 import torch
 
-from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+from . import ref_exec, unet_oracle as uo, diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def seeded_noise_fn(seed):
@@ -30,7 +30,7 @@ def main():
     out = {}
     hp = uo.ffhq_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     g = torch.Generator().manual_seed(11)
     x = torch.randn((1, 3, 256, 256), generator=g)
     t = torch.tensor([417])
@@ -44,7 +44,7 @@ def main():
     cfg = do.LoopConfig("deblur", 4, 12.75 / 255, 7.0, 0.3)
     y, k = torch.from_numpy(case["y"]), torch.from_numpy(case["k"])
     with torch.no_grad():
-        ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(51)).numpy()
+        ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(51)).numpy()
         ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(51)).numpy()
         # the reference's OWN fp32 rounding noise on this case: distance to the same loop with the (ill-conditioned) closed-form
         # prox evaluated in float64 -- the yardstick of the conditioning-aware parity bound (tests/gpu_common.py::fft_prox_parity)
@@ -58,12 +58,12 @@ def main():
     # schedule corner cases on the tiny UNet, inputs of tests/golden/loops.npz
     hp = uo.tiny_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     lg = np.load(os.path.join(OUT, "loops.npz"))
     y, mask = torch.from_numpy(lg["inpaint_y"]), torch.from_numpy(lg["inpaint_mask"])
     cfg = do.LoopConfig(task="inpaint", iter_num=8, noise_level_img=0.0, lambda_=1.0, zeta=1.0, noise_init_img=60.0)
     with torch.no_grad():
-        ref = live_reference.restore_live(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(52)).numpy()
+        ref = ref_exec.restore_ref(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(52)).numpy()
         ora = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(52)).numpy()
     out.update(tstart_out=ref, tstart_seed=np.array(52), tstart_noise_init_img=np.array(60.0))
     print("t_start loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()))
@@ -73,7 +73,7 @@ def main():
     n_last = sum(1 for s_ in seq if s_ == seq[-1])
     assert n_last >= 2, n_last
     with torch.no_grad():
-        ref = live_reference.restore_live(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(53)).numpy()
+        ref = ref_exec.restore_ref(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(53)).numpy()
         ora = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(53)).numpy()
     out.update(duplast_out=ref, duplast_seed=np.array(53), duplast_n_last=np.array(n_last))
     print("duplicate-last loop (", n_last, "final steps): live reference vs oracle max abs diff", float(np.abs(ref - ora).max()))

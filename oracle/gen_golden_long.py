@@ -21,9 +21,9 @@ import time
 import numpy as np
 import torch
 
-from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+from . import ref_exec, unet_oracle as uo, diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 C3_NFE, C5_NFE = 20, 8
 
 
@@ -41,7 +41,7 @@ def loop_case(out, tag, hp, sd, model, diffusion, size, nfe, seed_case, seed_noi
     lab = None if label is None else torch.tensor([label])
     t0 = time.time()
     with torch.no_grad():
-        ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), y_label=lab).numpy()
+        ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), y_label=lab).numpy()
         print(tag, "live reference", round(time.time() - t0, 1), "s", flush=True)
         ora = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), y_label=lab).numpy()
         exact = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(seed_noise), exact_prox=True, y_label=lab).numpy()
@@ -66,7 +66,7 @@ def main():
 
     hp = uo.imagenet256_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     x = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(31))
     t = torch.tensor([333])
     with torch.no_grad():
@@ -80,7 +80,7 @@ def main():
 
     hp = uo.imagenet512_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     x = torch.randn((1, 3, 64, 64), generator=torch.Generator().manual_seed(32))
     t, lab = torch.tensor([480]), torch.tensor([417])
     with torch.no_grad():

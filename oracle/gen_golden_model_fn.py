@@ -5,16 +5,16 @@ import os
 import numpy as np
 import torch
 
-from . import live_reference, ref_import, unet_oracle as uo
+from . import ref_exec, ref_import, unet_oracle as uo
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def main():
     ns = ref_import.load()
     hp = uo.tiny_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     betas = torch.from_numpy(np.linspace(0.0001, 0.02, 1000, dtype=np.float32))        # main_ddpir.py:184-190
     alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)
     g = torch.Generator().manual_seed(11)
@@ -26,7 +26,7 @@ def main():
             def noise_fn(t):
                 draws.append(1)
                 return torch.zeros_like(t)
-            with live_reference.patched_randn_like(noise_fn), torch.no_grad():
+            with ref_exec.patched_randn_like(noise_fn), torch.no_grad():
                 x0 = ns.utils_model.model_fn(x, noise_level=float(sig) * 255, model_out_type="pred_xstart", model_diffusion=model,
                                              diffusion=diffusion, ddim_sample=ddim, alphas_cumprod=alphas_cumprod)
             out[f"x0_{j}_{'ddim' if ddim else 'psample'}"] = x0.numpy()

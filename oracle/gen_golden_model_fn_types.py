@@ -12,9 +12,9 @@ import os
 import numpy as np
 import torch
 
-from . import live_reference, ref_import, unet_oracle as uo, diffpir_oracle as do
+from . import ref_exec, ref_import, unet_oracle as uo, diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     ns = ref_import.load()
     hp = uo.tiny_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     betas = torch.from_numpy(np.linspace(0.0001, 0.02, 1000, dtype=np.float32))        # main_ddpir.py:184-190
     alphas_cumprod = np.cumprod((1.0 - betas).cpu(), axis=0)
     g = torch.Generator().manual_seed(12)
@@ -33,7 +33,7 @@ def main():
         for ddim in (False, True):
             tag = f"{j}_{'ddim' if ddim else 'psample'}"
             for typ in ("pred_x_prev_and_start", "epsilon", "score"):
-                with live_reference.patched_randn_like(lambda t: noise.clone()), torch.no_grad():
+                with ref_exec.patched_randn_like(lambda t: noise.clone()), torch.no_grad():
                     r = ns.utils_model.model_fn(x, noise_level=float(sig) * 255, model_out_type=typ, model_diffusion=model,
                                                 diffusion=diffusion, ddim_sample=ddim, alphas_cumprod=alphas_cumprod)
                 if typ == "pred_x_prev_and_start":
@@ -41,7 +41,7 @@ def main():
                 else:
                     out[f"{typ}_{tag}"] = r.numpy()
     # DPS_y0 with ddim_sample=True through the reference's own model_fn / Resizer / grad_and_value
-    model, diffusion = live_reference.build_unet(hp, sd, frozen=False)
+    model, diffusion = ref_exec.build_unet(hp, sd, frozen=False)
     case = synth.make_case("sr", 2, 64, 64, seed=3, sf=4)
     cfg = do.LoopConfig("sr", 5, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0", ddim_sample=True)
     y, k = torch.from_numpy(case["y"]), torch.from_numpy(case["k"])
@@ -49,7 +49,7 @@ def main():
     def seeded(seed):
         gg = torch.Generator().manual_seed(seed)
         return lambda like: torch.randn(like.shape, generator=gg, dtype=torch.float32)
-    ref = live_reference.restore_live(model, diffusion, cfg, y, k=k, noise_fn=seeded(84)).numpy()
+    ref = ref_exec.restore_ref(model, diffusion, cfg, y, k=k, noise_fn=seeded(84)).numpy()
     ora = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded(84)).numpy()
     out.update(dpsddim_y=case["y"], dpsddim_gt=case["gt"], dpsddim_out=ref, dpsddim_seed=np.array(84), dpsddim_nfe=np.array(5))
     print("DPS_y0 + ddim_sample 5-NFE loop: live reference vs oracle max abs diff", float(np.abs(ref - ora).max()), "range", float(np.abs(ref).max()))

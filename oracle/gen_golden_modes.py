@@ -6,9 +6,9 @@ import os
 import numpy as np
 import torch
 
-from . import live_reference, unet_oracle as uo, diffpir_oracle as do
+from . import ref_exec, unet_oracle as uo, diffpir_oracle as do
 
-OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+OUT = os.environ.get("DIFFPIR_GOLDEN_OUT") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
 
 
 def seeded_noise_fn(seed):
@@ -19,14 +19,14 @@ def seeded_noise_fn(seed):
 def main():
     hp = uo.tiny_hp()
     sd = uo.synth_state_dict(hp, 0)
-    model, diffusion = live_reference.build_unet(hp, sd)
+    model, diffusion = ref_exec.build_unet(hp, sd)
     g = np.load(os.path.join(OUT, "loops.npz"))
     y, mask = torch.from_numpy(g["inpaint_y"]), torch.from_numpy(g["inpaint_mask"])
     out = {}
     for mode, seed in (("repaint", 45), ("vanilla", 46)):
         cfg = do.LoopConfig(task="inpaint", iter_num=6, noise_level_img=0.0, lambda_=1.0, zeta=1.0, generate_mode=mode)
         with torch.no_grad():
-            ref = live_reference.restore_live(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(seed)).numpy()
+            ref = ref_exec.restore_ref(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(seed)).numpy()
             ora = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(seed)).numpy()
         out[f"inpaint_{mode}_out"] = ref
         out[f"inpaint_{mode}_seed"] = np.array(seed)
@@ -34,7 +34,7 @@ def main():
     # skip_type: uniform (main_ddpir.py:328-331: seq = [i*skip] + [T-1]) on the DiffPIR inpainting loop, 5 + 1 steps
     cfg = do.LoopConfig(task="inpaint", iter_num=5, noise_level_img=0.0, lambda_=1.0, zeta=1.0, skip_type="uniform")
     with torch.no_grad():
-        ref = live_reference.restore_live(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(47)).numpy()
+        ref = ref_exec.restore_ref(model, diffusion, cfg, y, mask=mask, noise_fn=seeded_noise_fn(47)).numpy()
         ora = do.restore(sd, hp, cfg, y, mask=mask, noise_fn=seeded_noise_fn(47)).numpy()
     out["inpaint_uniform_out"] = ref
     out["inpaint_uniform_seed"] = np.array(47)

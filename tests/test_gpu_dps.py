@@ -173,7 +173,7 @@ def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
         e.set_precision("f16x3")
         make_model(e, hp)
         scale = float(np.abs(g["dpsyt_out"]).max())
-        cfg = restore.LoopConfig(task="sr", iter_num=10, lambda_=600.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
+        cfg = restore.LoopConfig(task="sr", iter_num=10, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt")
         out = restore.restore_batch(e, cfg, g["dps_y"], noise_source="host", noise_fn=seeded_noise_fn_np(int(g["dpsyt_seed"]))).numpy()
         err = float(np.abs(out - g["dpsyt_out"]).max())
         print(f"DPS_yt vs LIVE reference: max|diff| {err:.3e} (output range {scale:.2f})")
@@ -248,7 +248,7 @@ def test_stepwise_plug_loops_equal_the_monolithic_loops(golden, mode):
                 "DPS_y0+ddim": (restore.LoopConfig(task="sr", iter_num=int(gt2["dpsddim_nfe"]), lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic",
                                                    generate_mode="DPS_y0", ddim_sample=True),
                                 gt2["dpsddim_y"], int(gt2["dpsddim_seed"]), gt2["dpsddim_out"], 2e-4),
-                "DPS_yt": (restore.LoopConfig(task="sr", iter_num=10, lambda_=600.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0),
+                "DPS_yt": (restore.LoopConfig(task="sr", iter_num=10, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt"),
                            g["dps_y"], int(g["dpsyt_seed"]), g["dpsyt_out"], 1e-4 * max(1.0, float(np.abs(g["dpsyt_out"]).max()))),
                 "first_order": (restore.LoopConfig(task="sr", iter_num=6, lambda_=6.0e5, zeta=0.25, sf=4, sr_mode="cubic", sub_1_analytic=False),
                                 g["dps_y"], int(g["fo_seed"]), g["fo_out"], 1e-4)}

@@ -68,7 +68,7 @@ def test_library_exports_every_declared_symbol():
     missing = [n for n in sorted(declared) if not hasattr(lib, n)]
     assert not missing, missing
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert lib.dpir_version() == 1
+    assert lib.dpir_version() == _lib.ABI_VERSION == 2
     # the development-only header (probes and the isolated conv bench) resolves from its OWN library; the product library exports
     # none of it
     dbg = open(os.path.join(ROOT, "include", "diffpir_debug.h")).read()

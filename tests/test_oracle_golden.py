@@ -314,7 +314,7 @@ def test_dps_tables_vjp_and_loop_match_live_reference(golden):
     ng = [v for n, _, v in tr if n == "norm_grad"][0]
     np.testing.assert_allclose(ng.numpy(), g["dps_norm_grad0"], rtol=0, atol=1e-6)
     y = torch.from_numpy(g["dps_y"])
-    cfg = do.LoopConfig("sr", 10, 12.75 / 255, 600.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt", noise_init_img=100.0)
+    cfg = do.LoopConfig("sr", 10, 12.75 / 255, 6.0, 0.25, sf=4, sr_mode="cubic", generate_mode="DPS_yt")
     out = do.restore_dps_y0(sd, hp, cfg, y, noise_fn=seeded_noise_fn(int(g["dpsyt_seed"])))
     np.testing.assert_allclose(out.numpy(), g["dpsyt_out"], rtol=0, atol=2e-5)
     cfg = do.LoopConfig("sr", 6, 12.75 / 255, 6.0e5, 0.25, sf=4, sr_mode="cubic", sub_1_analytic=False)
