@@ -274,6 +274,7 @@ def main():
     fence()
     elapsed = ddist.max_over_ranks(time.perf_counter() - t0, device=None if backend == "gloo" else f"cuda:{local_rank}")
     coll_name = ddist.collective_name()
+    ranks_info = ddist.gather_rank_info(eng, local_rank)     # every rank's device / RCCL version, moved by the same collective as the results
     value = B * world * args.steps / elapsed
     headline_out = out_f32.numpy()           # before the instrumented passes below reuse the buffer
 
@@ -451,7 +452,7 @@ def main():
                 "config": {"workload": f"{cfg_tag}: {args.model} topology {H}x{H} {args.task} ({psf}), {args.nfe} NFE, "
                                        f"batch {B}/GPU, device Philox noise, hipGraph={'off' if args.no_graph else 'on'}",
                            "global_batch": B * world, "nfe": args.nfe, "sharding": f"images x{world}, all_gather(u8) of results",
-                           "collective": coll_name},
+                           "collective": coll_name, "ranks": ranks_info},
                 "roofline": roofline, "roofline_prox": prox, "degrade_metrics": f1, "dps_y0": dps, "cpu_baseline": cpu, "config_c3": c3, "alt_precision": alt, "reduced_precision": reduced}
         print(json.dumps(line))
     ddist.shutdown()

@@ -104,6 +104,8 @@ SIGNATURES = {
     "dpir_randn": (C.c_int, [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int]),
     "dpir_ewise": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_void_p, C.c_size_t]),
     "dpir_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "dpir_comm_version": (C.c_int, [C.POINTER(C.c_int)]),
+    "dpir_device_info": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "dpir_comm_init": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "dpir_allgather_results": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t]),
     "dpir_comm_allreduce_max": (C.c_int, [C.c_void_p, C.POINTER(C.c_double)]),

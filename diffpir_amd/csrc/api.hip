@@ -163,6 +163,16 @@ int dpir_device_count(int* n_out) {
     return DPIR_OK;
 }
 
+int dpir_device_info(dpir_engine* e, char* buf, size_t cap) {
+    if (!e || !buf || cap == 0) return DPIR_ERR_INVALID;
+    hipDeviceProp_t p;
+    if (hipGetDeviceProperties(&p, e->device) != hipSuccess) return fail(e, Status{DPIR_ERR_HIP, "hipGetDeviceProperties failed"});
+    char bus[32] = "?";
+    (void)hipDeviceGetPCIBusId(bus, sizeof(bus), e->device);
+    snprintf(buf, cap, "%s | %s | pci %s | %d CUs | ordinal %d", p.gcnArchName, p.name, bus, p.multiProcessorCount, e->device);
+    return DPIR_OK;
+}
+
 int dpir_create(int device, dpir_engine** out) {
     if (!out) return DPIR_ERR_INVALID;
     *out = nullptr;
@@ -239,9 +249,11 @@ int dpir_h2d(dpir_engine* e, void* d, const void* h, size_t bytes) {
 }
 int dpir_d2h(dpir_engine* e, void* h, const void* d, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;
+    // the guard word FIRST: a fused-hop time-out re-issues the invalidated forward (dpir_check_range), and the copy must see its result
+    if (int rc = check_range(e)) return rc;
     API_HIP(e, hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, e->stream));
     API_HIP(e, hipStreamSynchronize(e->stream));
-    return check_range(e);
+    return DPIR_OK;
 }
 int dpir_d2d(dpir_engine* e, void* dd, const void* ds, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;

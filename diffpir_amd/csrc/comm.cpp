@@ -19,6 +19,7 @@ struct Rccl {
     int (*AllGather)(const void*, void*, size_t, int, Comm, hipStream_t) = nullptr;
     int (*AllReduce)(const void*, void*, size_t, int, int, Comm, hipStream_t) = nullptr;
     int (*CommDestroy)(Comm) = nullptr;
+    int (*GetVersion)(int*) = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
     std::string err;
     std::mutex mu;
@@ -36,6 +37,7 @@ struct Rccl {
         AllReduce = reinterpret_cast<decltype(AllReduce)>(dlsym(lib, "ncclAllReduce"));
         CommDestroy = reinterpret_cast<decltype(CommDestroy)>(dlsym(lib, "ncclCommDestroy"));
         GetErrorString = reinterpret_cast<decltype(GetErrorString)>(dlsym(lib, "ncclGetErrorString"));
+        GetVersion = reinterpret_cast<decltype(GetVersion)>(dlsym(lib, "ncclGetVersion"));
         if (!GetUniqueId || !CommInitRank || !AllGather || !AllReduce || !CommDestroy) { err = "librccl.so lacks an expected symbol"; lib = nullptr; return false; }
         return true;
     }
@@ -70,6 +72,14 @@ int dpir_comm_unique_id(void* id128_out) {
     if (g_rccl.GetUniqueId(&id) != 0) return DPIR_ERR_HIP;
     memcpy(id128_out, id.internal, 128);
     return DPIR_OK;
+}
+
+// ncclGetVersion of the librccl.so this process bound (e.g. 22203), for the self-diagnosing bench line; DPIR_ERR_UNSUPPORTED without librccl
+int dpir_comm_version(int* version_out) {
+    if (!version_out) return DPIR_ERR_INVALID;
+    *version_out = 0;
+    if (!g_rccl.load() || !g_rccl.GetVersion) return DPIR_ERR_UNSUPPORTED;
+    return g_rccl.GetVersion(version_out) == 0 ? DPIR_OK : DPIR_ERR_HIP;
 }
 
 int dpir_comm_init(dpir_engine* e, int world, int rank, const void* id128) {

@@ -205,6 +205,7 @@ struct Conv8Args {
     int B = 0, C = 0, Cout = 0, H = 0, W = 0;
     unsigned long long* range_ctr = nullptr;
     bool x1 = false;                           // single-product mode (f16x1)
+    bool silu = true;                          // the table's activation flag (prm.w); the kernel is built for SiLU
 };
 bool conv8_supported(int B, int C, int Cout, int H, int W);
 Status launch_conv8(hipStream_t s, const Conv8Args& a);

@@ -79,17 +79,23 @@ __global__ __launch_bounds__(256, 2) void conv8_fused_kernel(Conv8K p) {
         const bool ok = item < C8_ITEMS && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         goff[it] = ok ? g * 8 * HW + gy * p.W + gx : -1;
         sidx[it] = item < C8_ITEMS ? item : -1;
-        grp[it] = g;
+        grp[it] = g < C8_KG ? g : 0;
     }
     const float* ximg = p.x + (size_t)n * p.C * HW;
 
+    // BRANCH-FREE on purpose.  The first version guarded every load and every element's transform with `goff >= 0` / the SiLU flag: the compiler
+    // turned each of the 48 elements per step into its own basic block with an `s_waitcnt lgkmcnt(0)` (the GroupNorm table read) in front
+    // of a branch -- 400 us per launch at B = 16 (profiles/r05/conv8_first_version_kernel_trace.txt).  Here every lane loads (out-of-image
+    // items read offset 0 of their plane, a valid address) and the padding zero is a select at the end.
     float v[C8_NIT][8];
     auto prefetch = [&](int ks) __attribute__((always_inline)) {
         const float* xs = ximg + (size_t)ks * 32 * HW;
 #pragma unroll
-        for (int it = 0; it < C8_NIT; ++it)
+        for (int it = 0; it < C8_NIT; ++it) {
+            const int o = goff[it] >= 0 ? goff[it] : grp[it] * 8 * HW;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) v[it][j] = goff[it] >= 0 ? xs[goff[it] + j * HW] : 0.f;
+            for (int j = 0; j < 8; ++j) v[it][j] = xs[o + j * HW];
+        }
     };
     prefetch(0);
 
@@ -109,32 +115,33 @@ __global__ __launch_bounds__(256, 2) void conv8_fused_kernel(Conv8K p) {
             const int i = q * 256 + tid;
             if (i < C8_WFR) s_w[i] = wsrc[i];
         }
-        // activations: GroupNorm affine + SiLU + split
+        // activations: GroupNorm affine + SiLU + split (the layer always activates: launch_conv8 refuses a table without the SiLU flag)
 #pragma unroll
         for (int it = 0; it < C8_NIT; ++it) {
-            if (sidx[it] < 0) continue;
             half8 h8, l8;
             const int c0 = ks * 32 + grp[it] * 8;
+            const bool inside = goff[it] >= 0;
+            float4 m[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) m[j] = s_prm[c0 + j];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float t = 0.f;
-                if (goff[it] >= 0) {
-                    const float4 m = s_prm[c0 + j];
-                    t = (v[it][j] - m.x) * m.y + m.z;
-                    if (m.w != 0.f) t = silu8(t);
-                }
+                float t = silu8((v[it][j] - m[j].x) * m[j].y + m[j].z);
+                t = inside ? t : 0.f;
                 bad |= !(fabsf(t) <= 65000.f);
                 t = fminf(fmaxf(t, -65000.f), 65000.f);
                 const _Float16 hh = (_Float16)t;
                 h8[j] = hh;
                 l8[j] = (_Float16)(t - (float)hh);
             }
-            s_hi[sidx[it]] = h8;
-            if (!X1) s_lo[sidx[it]] = l8;
+            if (sidx[it] >= 0) {
+                s_hi[sidx[it]] = h8;
+                if (!X1) s_lo[sidx[it]] = l8;
+            }
         }
         if (ks + 1 < ksteps) prefetch(ks + 1);     // in flight during the MFMAs below
         barrier_lds_only();                        // LDS writes of every wave landed; the prefetch is NOT waited for
-#pragma unroll
+#pragma unroll 3      // full unrolling spills (the GroupNorm table reads of the transform phase are hoisted: ~190 VGPRs live there)
         for (int tap = 0; tap < 9; ++tap) {
             const int dy = tap / 3, dx = tap - dy * 3;
             const half8 ah = s_w[(tap * 2 + 0) * 64 + lane];
@@ -178,6 +185,7 @@ bool conv8_supported(int B, int C, int Cout, int H, int W) {
 Status launch_conv8(hipStream_t s, const Conv8Args& a) {
     if (!conv8_supported(a.B, a.C, a.Cout, a.H, a.W)) return invalid("conv8: shape not supported");
     if (!a.x || !a.prm || !a.w || !a.bias || !a.out) return invalid("conv8: null operand");
+    if (!a.silu) return invalid("conv8: the fused prologue is GroupNorm + SiLU (the output layer); a table without activation takes the planes route");
     Conv8K k;
     k.x = a.x; k.prm = a.prm; k.w = reinterpret_cast<const half8*>(a.w); k.bias = a.bias; k.out = a.out;
     k.B = a.B; k.C = a.C; k.Cout = a.Cout; k.H = a.H; k.W = a.W;

@@ -114,6 +114,32 @@ def max_over_ranks(value: float, device=None) -> float:
     return value
 
 
+def rank_info(engine, local_rank: int) -> dict:
+    """What this rank runs on: device ordinal / name / PCI bus id (dpir_device_info), the librccl version the C ABI bound
+    (dpir_comm_version), pid and collective -- gathered by `gather_rank_info` into the bench line so that a multi-GPU run diagnoses itself."""
+    import ctypes as C
+    buf = C.create_string_buffer(200)
+    info = buf.value.decode() if engine.lib.dpir_device_info(engine.h, buf, 200) == 0 else "?"
+    v = C.c_int(0)
+    engine.lib.dpir_comm_version(C.byref(v))
+    return {"rank": _state["rank"], "world": _state["world"], "local_rank": local_rank, "device": info, "rccl_version": int(v.value),
+            "pid": os.getpid(), "collective": collective_name()}
+
+
+def gather_rank_info(engine, local_rank: int) -> list:
+    """Every rank's rank_info() on every rank: one all-gather of a fixed 512-byte JSON record per rank over the SAME collective as the
+    results (so the record itself proves the collective moved bytes between the listed devices)."""
+    import json
+    rec = json.dumps(rank_info(engine, local_rank)).encode()[:511]
+    world = _state["world"]
+    if _state["mode"] == "single" or world == 1:
+        return [json.loads(rec)]
+    send = engine.to_device(np.frombuffer(rec.ljust(512, b"\0"), np.uint8).reshape(1, 512).copy())
+    allr = all_gather_results(send, world, _state["rank"], world, engine=engine)
+    allr = allr if isinstance(allr, np.ndarray) else allr.numpy()
+    return [json.loads(bytes(allr[r]).rstrip(b"\0").decode()) for r in range(world)]
+
+
 def shutdown():
     if _state["mode"] == "rccl":
         barrier()

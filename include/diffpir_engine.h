@@ -52,6 +52,8 @@ int dpir_version(void);
 /* number of HIP devices visible to this process (0 when there is none; never fails).  The reference reads
  * torch.cuda.device_count() for its unused world_size (main_ddpir.py:135); the multi-GPU launcher and tests use this. */
 int dpir_device_count(int* n_out);
+/* "<gcnArchName> | <device name> | pci <bus id> | <CUs> CUs | ordinal <n>" of the engine's device into buf (NUL-terminated, truncated to cap) */
+int dpir_device_info(dpir_engine* e, char* buf, size_t cap);
 /* device = HIP ordinal.  Fails with DPIR_ERR_HIP when no gfx950 device is visible. */
 int dpir_create(int device, dpir_engine** out);
 void dpir_destroy(dpir_engine* e);
@@ -301,6 +303,8 @@ int dpir_grad_and_value(dpir_engine* e, int through_network, const float* x_hat_
  *                         them the N-GPU launch needs no other communication library;
  *   dpir_comm_destroy   : also done by dpir_destroy. */
 int dpir_comm_unique_id(void* id128_out);
+/* ncclGetVersion() of the bound librccl.so (diagnostics of the multi-GPU bench line); DPIR_ERR_UNSUPPORTED when librccl cannot be loaded */
+int dpir_comm_version(int* version_out);
 int dpir_comm_init(dpir_engine* e, int world, int rank, const void* id128);
 int dpir_allgather_results(dpir_engine* e, const void* send_dev, void* recv_dev, size_t bytes_per_rank);
 int dpir_comm_allreduce_max(dpir_engine* e, double* value_inout);

@@ -50,11 +50,20 @@ def nchw(t):
     return np.ascontiguousarray(t.numpy().transpose(0, 3, 1, 2))
 
 
-def floor_of(out, tag, hp, sd, cfg, y, k, seed, ref):
+def seeded_skip(seed, skip, shape):
+    """the stream of `seeded(seed)` after `skip` draws of `shape` (a later pass of the reference's sweep over one noise stream)"""
+    g = torch.Generator().manual_seed(seed)
+    for _ in range(skip):
+        torch.randn(shape, generator=g, dtype=torch.float32)
+    return lambda like: torch.randn(like.shape, generator=g, dtype=torch.float32)
+
+
+def floor_of(out, tag, hp, sd, cfg, y, k, seed, ref, skip=0, shape=None):
     """reference vs the same loop with an exact (float64) prox: the yardstick of tests/gpu_common.py::fft_prox_parity."""
+    nf = (lambda: seeded_skip(seed, skip, shape)) if skip else (lambda: seeded(seed))
     with torch.no_grad():
-        ora = do.restore(sd, hp, cfg, torch.from_numpy(y), k=torch.from_numpy(k), noise_fn=seeded(seed)).numpy()
-        exact = do.restore(sd, hp, cfg, torch.from_numpy(y), k=torch.from_numpy(k), noise_fn=seeded(seed), exact_prox=True).numpy()
+        ora = do.restore(sd, hp, cfg, torch.from_numpy(y), k=torch.from_numpy(k), noise_fn=nf()).numpy()
+        exact = do.restore(sd, hp, cfg, torch.from_numpy(y), k=torch.from_numpy(k), noise_fn=nf(), exact_prox=True).numpy()
     d = ref - exact
     out.update({f"{tag}_floor_max": np.array(np.abs(d).max()), f"{tag}_floor_rms": np.array(np.sqrt(np.mean(d * d)))})
     print(f"{tag}: reference main() vs oracle max abs diff {np.abs(ref - ora).max():.3e} | reference vs exact-prox loop: max {np.abs(d).max():.3e} "
@@ -98,6 +107,11 @@ def main():
         cfg = do.LoopConfig("deblur", nfe, 12.75 / 255, 1 * 7, 0.1 * 3)                             # the sweep's values (main_ddpir.py:565-568)
         floor_of(out, tag, hp_f, sd_f, cfg, out["c2lev_y"], kk, seed, x0)
 
+    if "c3floor4" in only:          # only the pass-4 floor of an existing c3bic record (no reference run)
+        hp_i = uo.imagenet256_hp()
+        sd_i = uo.synth_state_dict(hp_i, 0)
+        floor_of(out, "c3bic_p4", hp_i, sd_i, do.LoopConfig("sr", 4, 12.75 / 255, 6.0, 0.25, sf=4), out["c3bic_y"], out["c3bic_k"], 64,
+                 out["c3bic_out_pass4"], skip=4 * int(out["c3bic_draws_per_pass"]), shape=(1, 3, 256, 256))
     if not only or "c3bic" in only:
         t0 = time.time()
         hp_i = uo.imagenet256_hp()
@@ -114,6 +128,8 @@ def main():
         print(f"c3bic: reference main() (11-pass lambda sweep) {time.time() - t0:.0f} s, {noise.n // 11} draws per pass, y {out['c3bic_y'].shape}", flush=True)
         cfg = do.LoopConfig("sr", 4, 12.75 / 255, 2.0, 0.25, sf=4)
         floor_of(out, "c3bic", hp_i, sd_i, cfg, out["c3bic_y"], kk, 64, out["c3bic_out_pass0"])
+        floor_of(out, "c3bic_p4", hp_i, sd_i, do.LoopConfig("sr", 4, 12.75 / 255, 6.0, 0.25, sf=4), out["c3bic_y"], kk, 64,
+                 out["c3bic_out_pass4"], skip=4 * (noise.n // 11), shape=(1, 3, 256, 256))
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), flush=True)
 

@@ -39,14 +39,15 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("n_images", [8, 7])
-def test_sharded_results_equal_single_process(n_images):
-    world = 2
+@pytest.mark.parametrize("world,n_images", [(2, 8), (2, 7), (4, 7), (4, 3)])
+def test_sharded_results_equal_single_process(world, n_images):
+    """Even and ragged splits at world 2, and world 4 with a ragged 7-image batch (shards 2, 2, 2, 1) and with FEWER images than ranks
+    (3 over 4: one rank's shard is empty and it still has to join the collective)."""
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(_worker, args=(world, _free_port(), n_images, ret), nprocs=world, join=True)
     ref = fake_restore(0, n_images).numpy().tobytes()
-    assert ret[0] == ref and ret[1] == ref
+    assert all(ret[r] == ref for r in range(world))
 
 
 def _worker_api(rank, world, port, ret):

@@ -139,12 +139,12 @@ def test_fused_hop_is_offered_only_where_groups_stay_inside_a_wave():
     e = diffpir_amd.Engine(0)
     dbg = _lib.load_debug()
     cap = C.c_int(0)
-    assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, 256, 64, 64, C.byref(cap)) == 1
+    assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, 256, 128, 128, C.byref(cap)) == 1
     assert cap.value >= 2 and cap.value % 2 == 0
-    for cout in (128, 256, 512, 1024):
-        assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, cout, 64, 64, None) == 1, cout
+    for cout in (128, 256, 512, 1024):          # 128 x 128: 64 tiles per image, >= 384 workgroups at B = 16 for every width
+        assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, cout, 128, 128, None) == 1, cout
     for cout in (384, 640, 768, 896):
-        assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, cout, 64, 64, None) == 0, cout
+        assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, cout, 128, 128, None) == 0, cout
     # a waiting set larger than half the resident workgroups is refused: 512 x 512 has 1024 tiles per image
     assert dbg.dpir_debug_conv7_emit_supported(e.h, 16, 128, 512, 512, None) == (1 if 1024 <= cap.value // 2 else 0)
     e.close()

@@ -306,3 +306,28 @@ def test_gradient_mode_plugs_refuse_what_they_cannot_do_before_touching_the_devi
         utils_model.model_fn(None, 10.0, None, vec_t=np.array([5, 5]), model_out_type="epsilon", diffusion=D, alphas_cumprod=ac)
     with pytest.raises(NotImplementedError, match="per-sample"):
         utils_model.model_fn(None, 10.0, None, vec_t=np.array([5, 6]), model_out_type="pred_xstart", diffusion=D, alphas_cumprod=ac)
+
+
+def test_yaml_driver_reads_the_reference_kernel_files(tmp_path):
+    """diffpir_amd.main_ddpir.make_operators honours `use_DIY_kernel: false` (Levin09[0] out of <cwd>/kernels) and reads the sr PSF from
+    kernels_bicubicx234.mat when the file is there; the arrays equal what the reference's dataset handed to test_rho."""
+    from diffpir_amd import main_ddpir as drv
+    g = np.load(os.path.join(ROOT, "tests", "golden", "refdata.npz"))
+    kdir = tmp_path / "kernels"
+    kdir.mkdir()
+    import scipy.io
+    cell = np.empty((1, 3), dtype=object)
+    for i in range(3):
+        cell[0, i] = g["c3bic_k"][0, 0].astype(np.float64) if i == 2 else np.zeros((25, 25))
+    scipy.io.savemat(str(kdir / "kernels_bicubicx234.mat"), {"kernels": cell})
+    np.savez(str(kdir / "Levin09.npz"), k0=g["c2lev_k"][0, 0].astype(np.float64), k1=np.zeros((17, 17)))
+    # a v7.3 header (version word 0x0200, 'IM'): scipy refuses it ("Please use HDF reader") -> h5py is absent here -> the .npz sidecar is used
+    (kdir / "Levin09.mat").write_bytes(b"MATLAB 7.3 MAT-file, Platform: test".ljust(124, b" ") + b"\x00\x02IM" + b"\0" * 512)
+    cfg = drv.Config(dict(cwd=str(tmp_path), task="sr", sf=4))
+    k, _ = drv.make_operators(cfg, 2, 0, 256, 256)
+    assert k.shape == (2, 1, 25, 25) and np.array_equal(k[1, 0], g["c3bic_k"][0, 0])
+    cfg = drv.Config(dict(cwd=str(tmp_path), task="deblur", use_DIY_kernel=False, blur_mode="Gaussian", kernel_size=61))
+    k, _ = drv.make_operators(cfg, 3, 0, 256, 256)
+    assert k.shape == (3, 1, 19, 19) and np.array_equal(k[2, 0], g["c2lev_k"][0, 0])
+    with pytest.raises(FileNotFoundError):
+        drv.make_operators(drv.Config(dict(cwd=str(tmp_path / "nowhere"), task="deblur", use_DIY_kernel=False)), 1, 0, 256, 256)

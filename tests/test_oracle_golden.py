@@ -321,3 +321,17 @@ def test_dps_tables_vjp_and_loop_match_live_reference(golden):
     k = torch.from_numpy(synth.make_case("sr", 2, 64, 64, seed=3, sf=4)["k"])
     out = do.restore(sd, hp, cfg, y, k=k, noise_fn=seeded_noise_fn(int(g["fo_seed"])))
     np.testing.assert_allclose(out.numpy(), g["fo_out"], rtol=0, atol=2e-5)
+
+
+def test_oracle_equals_the_reference_main_run_on_shipped_inputs_bit_for_bit(golden):
+    """tests/golden/refdata.npz `c2lev_*`: the reference's main() executed end to end (oracle/ref_exec.run_main) on the five demo PNGs with
+    kernels/Levin09.mat[0, 0], lambda / zeta from its own sweep, 4 NFE on the FFHQ topology.  Fed the batch DataLoader handed to test_rho
+    (with the loader's channels-last strides, do.loader_strides) and the same noise stream, the oracle restatement reproduces x_0 EXACTLY
+    (measured 0.0 at generation for all four cases of the file; this one is cheap enough for the CPU suite)."""
+    g = golden("refdata")
+    hp = uo.ffhq_hp()
+    sd = uo.synth_state_dict(hp, 0)
+    cfg = do.LoopConfig("deblur", int(g["c2lev_nfe"]), 12.75 / 255, 1 * 7, 0.1 * 3)
+    with torch.no_grad():
+        out = do.restore(sd, hp, cfg, torch.from_numpy(g["c2lev_y"]), k=torch.from_numpy(g["c2lev_k"]), noise_fn=seeded_noise_fn(int(g["c2lev_seed"]))).numpy()
+    assert np.array_equal(out, g["c2lev_out"]), float(np.abs(out - g["c2lev_out"]).max())
