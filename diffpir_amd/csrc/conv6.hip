@@ -585,12 +585,14 @@ Status launch_conv6(hipStream_t s, const Conv6Args& a, int* stat_kind_out, Pendi
     k.n_co_blocks = (a.Cout + 127) / 128;
     const int chunks = k.n_chunks_total;
     const int blocks = n_ptiles * k.n_co_blocks;
-    // split-K when the launch cannot give every CU its two workgroups (low-resolution layers); deterministic slabs.  The two constants
-    // are tuning knobs (A/B switches for tools/layer_roofline.py and tools/forward_time.py, read once): split launches with fewer
-    // than DPIR_SPLIT_BELOW workgroups so that about DPIR_SPLIT_TARGET result.  Every slice writes a full fp32 slab, so a lower target
-    // trades co-resident workgroups for slab traffic (per-shape figures: DESIGN.md section 6).
-    static const int split_below = getenv("DPIR_SPLIT_BELOW") ? atoi(getenv("DPIR_SPLIT_BELOW")) : 384;
-    static const int split_target = getenv("DPIR_SPLIT_TARGET") ? atoi(getenv("DPIR_SPLIT_TARGET")) : 512;
+    // split-K when the launch cannot give every CU ONE workgroup (low-resolution layers); deterministic slabs.  Every slice writes a full fp32
+    // slab, so splitting trades co-resident workgroups for slab traffic.  Rounds 2-4 split below 384 workgroups up to ~512 ("two per CU");
+    // measured in round 5 (profiles/r05/split_rule_layer_roofline_and_forward_ab.log, five settings interleaved in one call): splitting only
+    // below 256 up to ~256 is faster on every affected shape -- 512 -> 512 @ 32^2 215 -> 185 us, 256 -> 256 @ 32^2 65 -> 60, 512 -> 512 @ 16^2
+    // 64 -> 58.5, 1024 -> 512 @ 16^2 108 -> 99 -- and 18.88 -> 18.73 ms per forward; larger targets (768, 1024) lose 0.7 ms.  The two constants stay
+    // read-once environment knobs for A/B runs (tools/layer_roofline.py, tools/forward_time.py).
+    static const int split_below = getenv("DPIR_SPLIT_BELOW") ? atoi(getenv("DPIR_SPLIT_BELOW")) : 256;
+    static const int split_target = getenv("DPIR_SPLIT_TARGET") ? atoi(getenv("DPIR_SPLIT_TARGET")) : 256;
     int S = 1;
     if (k.partial && blocks < split_below) {
         S = (split_target + blocks - 1) / blocks;

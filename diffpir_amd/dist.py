@@ -134,10 +134,13 @@ def gather_rank_info(engine, local_rank: int) -> list:
     world = _state["world"]
     if _state["mode"] == "single" or world == 1:
         return [json.loads(rec)]
-    send = engine.to_device(np.frombuffer(rec.ljust(512, b"\0"), np.uint8).reshape(1, 512).copy())
-    allr = all_gather_results(send, world, _state["rank"], world, engine=engine)
-    allr = allr if isinstance(allr, np.ndarray) else allr.numpy()
-    return [json.loads(bytes(allr[r]).rstrip(b"\0").decode()) for r in range(world)]
+    try:
+        send = engine.to_device(np.frombuffer(rec.ljust(512, b"\0"), np.uint8).reshape(1, 512).copy())
+        allr = all_gather_results(send, world, _state["rank"], world, engine=engine)
+        allr = allr if isinstance(allr, np.ndarray) else allr.numpy()
+        return [json.loads(bytes(allr[r]).rstrip(b"\0").decode()) for r in range(world)]
+    except Exception as ex:          # diagnostics must never cost the run its result line
+        return [json.loads(rec), {"gather_error": repr(ex)[:200]}]
 
 
 def shutdown():

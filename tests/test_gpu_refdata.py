@@ -64,13 +64,13 @@ def test_c2_levin09_deblurring_of_the_demo_images_matches_the_reference_run(ffhq
     out = restore.restore_batch(e, cfg, ref["c2lev_y"], k=ref["c2lev_k"], noise_source="host", noise_fn=seeded_noise_fn_np(int(ref[f"{tag}_seed"])),
                                 use_graph=True).numpy()
     fft_prox_parity(out, ref[f"{tag}_out"], _gt01(ref["c2lev_gt"]), f"C2 Levin09[0] on the 5 demo images, {nfe} NFE [{precision}] vs the reference's main()",
-                    floor=(float(ref[f"{tag}_floor_max"]), float(ref[f"{tag}_floor_rms"])), nfe=nfe)
+                    floor=(float(ref[f"{tag}_floor_max"]), float(ref[f"{tag}_floor_rms"])), nfe=nfe, floor_dpsnr=float(ref[f"{tag}_floor_dpsnr"]))
 
 
 @pytest.mark.parametrize("precision", ["f16x3", "f32"])
 def test_c3_bicubic_psf_sisr_of_a_demo_image_matches_the_reference_sweep(ref, precision):
     """BASELINE config 3's operator on a demo image: kernels_bicubicx234.mat[0, 2] read by the reference's dataset, ImageNet-256 topology,
-    4 NFE; main()'s sr sweep makes 11 passes (lambda 2 .. 12) over ONE noise stream -- pass 0 (lambda 2) and pass 4 (lambda 6) are compared,
+    12 NFE; main()'s sr sweep makes 11 passes (lambda 2 .. 12) over ONE noise stream -- pass 0 (lambda 2) and pass 4 (lambda 6) are compared,
     the latter after skipping the draws the first four passes consumed."""
     e = diffpir_amd.Engine(0)
     e.set_precision(precision)
@@ -87,6 +87,6 @@ def test_c3_bicubic_psf_sisr_of_a_demo_image_matches_the_reference_sweep(ref, pr
         out = restore.restore_batch(e, cfg, y, k=k, noise_source="host", noise_fn=nf, use_graph=True).numpy()
         tgt = ref[f"c3bic_out_pass{ps}"]
         ftag = "c3bic" if ps == 0 else "c3bic_p4"
-        fft_prox_parity(out, tgt, gt, f"C3 bicubic PSF on 69037.png, 4 NFE, sweep pass {ps} (lambda {lambdas[ps]:g}) [{precision}] vs the reference's main()",
-                        floor=(float(ref[f"{ftag}_floor_max"]), float(ref[f"{ftag}_floor_rms"])))
+        fft_prox_parity(out, tgt, gt, f"C3 bicubic PSF on 69037.png, {int(ref['c3bic_nfe'])} NFE, sweep pass {ps} (lambda {lambdas[ps]:g}) [{precision}] vs the reference's main()",
+                        floor=(float(ref[f"{ftag}_floor_max"]), float(ref[f"{ftag}_floor_rms"])), floor_dpsnr=float(ref[f"{ftag}_floor_dpsnr"]), nfe=int(ref["c3bic_nfe"]))
     e.close()
