@@ -52,9 +52,9 @@ def whole_forward(d, tag, forwards=3):
 d = sys.argv[1]
 src = f"{d}/<case>_pmc_{{FETCH,WRITE}}_SIZE.txt: separate rocprofv3 --pmc passes over tools/prof_forward.py (tools/gpu_prof_round.sh), FETCH_SIZE doubled per the gfx950 note of MI355X_MICROARCH.md, KB -> bytes, launch-weighted over the kernels of the class"
 out = {
-    "ffhq_B16_256_f16x3": klass(d, "ffhq_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel", src),
+    "ffhq_B16_256_f16x3": klass(d, "ffhq_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel|conv8_fused_kernel", src),
     "ffhq_B16_256_f32": klass(d, "ffhq_f32", r"conv2_mfma_kernel<3|conv2_mfma_kernel<1, 8|conv_mfma_kernel<3", src),
-    "imagenet256_B32_256_f16x3": klass(d, "in256_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel", src),
+    "imagenet256_B32_256_f16x3": klass(d, "in256_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel|conv8_fused_kernel", src),
     "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
     "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
 }
