@@ -62,8 +62,9 @@ int dpir_check_range(dpir_engine* e) {
         std::function<int()> replay = std::move(e->replay_last);
         e->fwd_since_sync = 0; e->replay_last = nullptr;
         if (burst != 1 || !replay)
-            return fail(e, Status{DPIR_ERR_HIP, "conv7 fused emission timed out during a burst of " + std::to_string(burst) + " un-synchronised forwards: their "
-                                                "results are invalid.  The hop is now off for this engine; re-issue the calls (not a sticky error)"});
+            return fail(e, Status{DPIR_ERR_HIP, "conv7 fused emission timed out " + (burst == 0 ? std::string("inside a loop call (dpir_run_dps_loop)") :
+                                                "during a burst of " + std::to_string(burst) + " un-synchronised forwards") + ": the results since the last "
+                                                "synchronisation are invalid.  The hop is now off for this engine; re-issue the call(s) (not a sticky error)"});
         if (int rc = replay()) return rc;
         e->fwd_since_sync = 0; e->replay_last = nullptr;
         if (int rc = read_range(e, &n)) return rc;
