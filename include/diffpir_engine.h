@@ -58,7 +58,13 @@ int dpir_device_info(dpir_engine* e, char* buf, size_t cap);
 int dpir_create(int device, dpir_engine** out);
 void dpir_destroy(dpir_engine* e);
 const char* dpir_last_error(const dpir_engine* e);   /* never NULL */
-int dpir_sync(dpir_engine* e);                       /* hipStreamSynchronize on the engine stream */
+/* hipStreamSynchronize on the engine stream, then the f16 operand range guard (DPIR_ERR_RANGE, above).  Also the point where a time-out of
+ * conv7's fused GroupNorm hop (an inter-workgroup wait; only seen when 3+ engines / processes share the GPU) is handled: the engine switches
+ * the hop off for its lifetime, re-issues the ONE eager forward (dpir_unet_forward / dpir_model_fn_xstart / dpir_p_sample) outstanding since
+ * the last synchronisation on the unfused path and returns DPIR_OK with correct results; a burst of several un-synchronised eager forwards
+ * cannot be re-issued from here and returns DPIR_ERR_HIP ONCE (not sticky: repeat the calls).  dpir_d2h does the same before it copies;
+ * dpir_run_loop re-runs itself. */
+int dpir_sync(dpir_engine* e);
 /* the engine's hipStream_t, for callers that enqueue their own work (e.g. RCCL) behind it */
 void* dpir_stream(dpir_engine* e);
 
