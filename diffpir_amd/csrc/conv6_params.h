@@ -14,7 +14,10 @@ struct Conv6Emit {
     long long* acc = nullptr;          // [B][32 groups][2] {sum * 2^20, sum of squares * 2^12}, zero before the launch
     unsigned* cnt = nullptr;           // [B][n_co_blocks] arrival counters, zero before the launch
     unsigned long long* range_ctr = nullptr;   // f16 operand range guard; a barrier time-out adds 2^40 to it
-    int spin_limit = 2000000;          // polls (~0.5 us each) before a waiting workgroup gives up and flags the guard word
+    int spin_limit = 250000;           // polls (~4 us each at the default interval: about a second) before a waiting workgroup gives up and flags the guard word
+    int sleep_sel = 5;                 // poll interval of the wait: s_sleep 2 / 8 / 16 / 32 / 64 / 127 (default) / 2 x 127 / 4 x 127, x 64 cycles (DPIR_FUSE_SLEEP=0..7, A/B knob).
+                                       // Round 5, two boxes, interleaved (profiles/r05/fused_hop_poll_interval_ab.log): 16 (rounds 4's value) 18.81 / 19.40 ms per forward, 127: 18.72 /
+                                       // 19.31, 254: 19.31, 508: 19.42 -- up to 255 waiting workgroups polling ONE word every ~0.5 us delay the arrivals' own atomics
     int expect_extra = 0;              // tests only (DPIR_FUSE_EXPECT_EXTRA): arrivals waited for beyond the image's workgroups -> forces the time-out
 };
 

@@ -311,7 +311,16 @@ __global__ __launch_bounds__(256, 2) void conv7_mfma_kernel(Conv6K p) {
                 asm volatile("" : : "v"(old));
                 int spins = 0;
                 while (__hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < (unsigned)(tiles_per_img + p.em.expect_extra)) {
-                    __builtin_amdgcn_s_sleep(16);
+                    switch (p.em.sleep_sel) {          // the argument of s_sleep is an immediate
+                        case 0: __builtin_amdgcn_s_sleep(2); break;
+                        case 1: __builtin_amdgcn_s_sleep(8); break;
+                        case 3: __builtin_amdgcn_s_sleep(32); break;
+                        case 4: __builtin_amdgcn_s_sleep(64); break;
+                        case 6: __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); break;
+                        case 7: __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); __builtin_amdgcn_s_sleep(127); break;
+                        case 2: __builtin_amdgcn_s_sleep(16); break;
+                        default: __builtin_amdgcn_s_sleep(127); break;
+                    }
                     if (++spins > p.em.spin_limit) { atomicAdd(p.em.range_ctr, 1ull << 40); break; }      // never hang the GPU: report through the range guard
                 }
             }

@@ -524,6 +524,8 @@ struct Fwd {
         // test hooks for the time-out path (tests/test_gpu_benched_batches.py): a short spin limit and an arrival count that cannot be reached
         static const int spin_env = getenv("DPIR_FUSE_SPIN_LIMIT") ? atoi(getenv("DPIR_FUSE_SPIN_LIMIT")) : 0;
         static const int extra_env = getenv("DPIR_FUSE_EXPECT_EXTRA") ? atoi(getenv("DPIR_FUSE_EXPECT_EXTRA")) : 0;
+        static const int sleep_env = getenv("DPIR_FUSE_SLEEP") ? atoi(getenv("DPIR_FUSE_SLEEP")) : 5;
+        em->sleep_sel = sleep_env;
         if (spin_env > 0) em->spin_limit = spin_env;
         em->expect_extra = extra_env;
         return Status{};
