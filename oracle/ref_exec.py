@@ -38,7 +38,6 @@ import os
 import subprocess
 import sys
 import tempfile
-import types
 from collections import OrderedDict
 
 import numpy as np
@@ -418,7 +417,6 @@ def run_main(ydict, state_dict, images, noise_fn=None, build_model=None):
                 ns["main"]()
         finally:
             sys.argv = argv
-            lg = logging.getLogger(ydict.get("_logger_name", ""))
     return dict(x0=captured, batches=batches)
 
 
