@@ -301,7 +301,9 @@ int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, con
     if (y_host && e->net.loaded)
         for (int i = 0; i < B; ++i)
             if (y_host[i] < 0 || y_host[i] >= e->net.desc.num_classes) return fail(e, invalid("class label out of range"));
-    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out, B, H, W));
+    bool uni = true;
+    for (int i = 1; i < B; ++i) uni = uni && t_host[i] == t_host[0];
+    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out, B, H, W, nullptr, nullptr, uni));
     if (!e->fuse_h1_off && !e->grad_enabled && e->precision != 0) {
         std::vector<int64_t> tv(t_host, t_host + B), yv;
         if (y_host) yv.assign(y_host, y_host + B);
@@ -322,7 +324,7 @@ int dpir_model_fn_xstart(dpir_engine* e, const float* x, int t, float c1, float 
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     float* out6 = nullptr;
     API_TRY(e, e->ws.getT("api#out6", (size_t)B * e->net.desc.out_channels * H * W, &out6));
-    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out6, B, H, W));
+    API_TRY(e, unet_forward(e, x, t_dev, y_dev, out6, B, H, W, nullptr, nullptr, true));
     ProfScope ps(&e->prof, PC_ELEM);
     API_TRY(e, launch_xstart(e->stream, x, out6, e->net.desc.out_channels, c1, c2, x0, B, H * W));
     if (!e->fuse_h1_off && !e->grad_enabled && e->precision != 0) {
@@ -1013,7 +1015,7 @@ static Status p_sample_impl(dpir_engine* e, const float* x, const int* t_dev, co
     if (oc != 6) return Status{DPIR_ERR_UNSUPPORTED, "p_sample needs a learn_sigma model (out_channels == 6): the learned-range variance is read from channels 3..5"};
     unsigned char* inside = nullptr;
     DPIR_TRY(e->ws.getT("dps#inside", (size_t)B * 3 * H * W, &inside));
-    DPIR_TRY(unet_forward(e, x, t_dev, y_dev, out6, B, H, W));
+    DPIR_TRY(unet_forward(e, x, t_dev, y_dev, out6, B, H, W, nullptr, nullptr, true));      // every caller passes one timestep for the whole batch
     ProfScope ps(&e->prof, PC_ELEM);
     DPIR_TRY(launch_psample(e->stream, x, out6, oc, noise, cf, x0, xt, inside, B, H * W));
     e->ps_c1 = cf.c1; e->ps_c2 = cf.c2; e->ps_B = B; e->ps_H = H; e->ps_W = W; e->ps_x0 = x0; e->ps_serial = e->fwd_serial;

@@ -684,7 +684,7 @@ Status unet_film_table(dpir_engine* e, const int* t_dev, int n_steps, float* tab
 }
 
 Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int* y_dev, float* out, int B, int H, int W,
-                    const float* film_table, const StepDev* film_step) {
+                    const float* film_table, const StepDev* film_step, bool uniform_t) {
     UNet& net = e->net;
     if (!net.loaded) return Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"};
     if ((net.desc.num_classes > 0) != (y_dev != nullptr))
@@ -696,20 +696,23 @@ Status unet_forward(dpir_engine* e, const float* x, const int* t_dev, const int*
     const int mc = net.desc.model_channels, ted = 4 * mc;
     float *tmp = nullptr, *semb = nullptr, *film = nullptr;
     const bool hoisted = film_table != nullptr && film_step != nullptr;
+    static const bool one_row_env = !(getenv("DPIR_UNIFORM_T") && atoi(getenv("DPIR_UNIFORM_T")) == 0);      // A/B switch
+    const bool one_row = one_row_env && !hoisted && uniform_t && net.desc.num_classes == 0 && y_dev == nullptr;
     if (hoisted && net.desc.num_classes > 0) return invalid("hoisted FiLM table with a class-conditional model");
     if (!hoisted) {
         DPIR_TRY(ws.getT("emb#tmp", (size_t)B * (mc + ted), &tmp));
         DPIR_TRY(ws.getT("emb#semb", (size_t)B * ted, &semb));
         DPIR_TRY(ws.getT("emb#film", (size_t)B * net.film_rows, &film));
         ProfScope ps(&e->prof, PC_ELEM);
-        DPIR_TRY(launch_time_embed(s, t_dev, y_dev, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, net.label_emb, B, mc, tmp, semb));
-        DPIR_TRY(launch_rows_gemv(s, net.film_w, net.film_b, semb, B, net.film_rows, ted, film));
+        const int Be = one_row ? 1 : B;          // uniform timestep, no labels: row 0 serves every image (film_stride 0 below)
+        DPIR_TRY(launch_time_embed(s, t_dev, y_dev, net.freqs, net.te_w0, net.te_b0, net.te_w2, net.te_b2, net.label_emb, Be, mc, tmp, semb));
+        DPIR_TRY(launch_rows_gemv(s, net.film_w, net.film_b, semb, Be, net.film_rows, ted, film));
     }
     // split-K slab: 16 slices of the largest low-resolution output (layers with < 384 workgroups)
     float* partial = nullptr;
     size_t partial_cap = (size_t)16 * 1024 * 1024;   // 64 MiB
     DPIR_TRY(ws.getT("conv#partial", partial_cap, &partial));
-    Fwd f{e, s, ws, B, hoisted ? film_table : film, net.film_rows, hoisted ? 0 : net.film_rows, hoisted ? film_step : nullptr, partial, partial_cap};
+    Fwd f{e, s, ws, B, hoisted ? film_table : film, net.film_rows, (hoisted || one_row) ? 0 : net.film_rows, hoisted ? film_step : nullptr, partial, partial_cap};
     {
         static const bool fuse_env = !(getenv("DPIR_FUSE_SMALL") && atoi(getenv("DPIR_FUSE_SMALL")) == 0);   // A/B switch (tools/, tests)
         static const int emit_env = getenv("DPIR_EMIT_SKIP") ? atoi(getenv("DPIR_EMIT_SKIP")) : 1;

@@ -54,6 +54,29 @@ def test_tiny_unet_batch_and_odd_batch(engine):
     _run_and_compare(engine, uo.tiny_hp(), 1, 32, 32)
 
 
+def test_uniform_timestep_shares_one_film_row(engine):
+    """Round 5: when every image of the batch has the same timestep (what model_fn always passes, utils_model.py:217) and the model is
+    class-unconditional, the time embedding and the FiLM projection are evaluated for ONE row and shared.  Same bits as the per-image rows
+    (a forward whose timesteps differ only in the LAST image takes the per-image route: its first images must come out identical), and the
+    oracle agrees."""
+    hp = uo.tiny_hp()
+    model, sd = make_model(engine, hp)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn((3, 3, 64, 64), generator=g)
+    xd = engine.to_device(x.numpy())
+    uni = engine.unet_forward(xd, np.array([321, 321, 321])).numpy()
+    mixed = engine.unet_forward(xd, np.array([321, 321, 17])).numpy()
+    assert np.array_equal(uni[:2], mixed[:2])
+    ref = uo.unet_forward(sd, hp, x, torch.tensor([321, 321, 321])).numpy()
+    assert rel_err(uni, ref) < TOL_OUT
+    # a class-conditional model never shares the row (labels differ per image)
+    hpc = uo.tiny_hp(class_cond=True)
+    make_model(engine, hpc)
+    a = engine.unet_forward(xd, np.array([50, 50, 50]), np.array([1, 2, 3])).numpy()
+    b = engine.unet_forward(xd, np.array([50, 50, 50]), np.array([1, 2, 9])).numpy()
+    assert np.array_equal(a[:2], b[:2]) and not np.array_equal(a[2], b[2])
+
+
 def test_tiny_unet_non_square(engine):
     _run_and_compare(engine, uo.tiny_hp(), 2, 32, 64)
 
