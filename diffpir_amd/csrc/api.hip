@@ -283,6 +283,19 @@ static Status upload_ints(dpir_engine* e, const char* name, const int64_t* host,
     return Status{};
 }
 
+// One timestep for the whole batch (what model_fn passes): written on the device by a 1-workgroup kernel -- no host buffer, no copy and, unlike
+// upload_ints, no hipStreamSynchronize, so back-to-back eager forwards are queued while the previous one still runs.
+__global__ void fill_const_kernel(int* p, int v, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+static Status fill_ints(dpir_engine* e, const char* name, int value, int B, int** dev) {
+    DPIR_TRY(e->ws.getT(name, (size_t)B, dev));
+    hipLaunchKernelGGL(fill_const_kernel, dim3((B + 255) / 256), dim3(256), 0, e->stream, *dev, value, B);
+    DPIR_HIP(hipGetLastError());
+    return Status{};
+}
+
 int dpir_set_precision(dpir_engine* e, int mode) {
     if (!e) return DPIR_ERR_INVALID;
     if (mode < 0 || mode > 2) return fail(e, invalid("dpir_set_precision: mode must be 0 (fp32 MFMA), 1 (operand-split f16x3 MFMA) or 2 (f16x1: f16 operands, fp32 accumulate)"));
@@ -296,13 +309,14 @@ int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, con
     (void)hipSetDevice(e->device);
     int *t_dev = nullptr, *y_dev = nullptr;
     range_clear(e);
-    API_TRY(e, upload_ints(e, "api#t", t_host, B, &t_dev));
+    bool uni = true;
+    for (int i = 1; i < B; ++i) uni = uni && t_host[i] == t_host[0];
+    if (uni && !y_host) API_TRY(e, fill_ints(e, "api#t", (int)t_host[0], B, &t_dev));
+    else API_TRY(e, upload_ints(e, "api#t", t_host, B, &t_dev));
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     if (y_host && e->net.loaded)
         for (int i = 0; i < B; ++i)
             if (y_host[i] < 0 || y_host[i] >= e->net.desc.num_classes) return fail(e, invalid("class label out of range"));
-    bool uni = true;
-    for (int i = 1; i < B; ++i) uni = uni && t_host[i] == t_host[0];
     API_TRY(e, unet_forward(e, x, t_dev, y_dev, out, B, H, W, nullptr, nullptr, uni));
     if (!e->fuse_h1_off && !e->grad_enabled && e->precision != 0) {
         std::vector<int64_t> tv(t_host, t_host + B), yv;
@@ -317,10 +331,9 @@ int dpir_model_fn_xstart(dpir_engine* e, const float* x, int t, float c1, float 
     if (!e || !x || !x0) return fail(e, invalid("dpir_model_fn_xstart: null argument"));
     (void)hipSetDevice(e->device);
     if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
-    std::vector<int64_t> tv(B, t);
     int *t_dev = nullptr, *y_dev = nullptr;
     range_clear(e);
-    API_TRY(e, upload_ints(e, "api#t", tv.data(), B, &t_dev));
+    API_TRY(e, fill_ints(e, "api#t", t, B, &t_dev));
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     float* out6 = nullptr;
     API_TRY(e, e->ws.getT("api#out6", (size_t)B * e->net.desc.out_channels * H * W, &out6));
@@ -1072,10 +1085,9 @@ int dpir_p_sample(dpir_engine* e, const float* x_dev, int t, const dpir_psample_
     if (!e->net.loaded) return fail(e, Status{DPIR_ERR_STATE, "dpir_load_unet has not been called"});
     if ((e->net.desc.num_classes > 0) != (y_host != nullptr)) return fail(e, invalid("labels iff class-conditional model"));
     range_clear(e);
-    std::vector<int64_t> tv(B, t);
     int *t_dev = nullptr, *y_dev = nullptr;
     float* out6 = nullptr;
-    API_TRY(e, upload_ints(e, "api#t", tv.data(), B, &t_dev));
+    API_TRY(e, fill_ints(e, "api#t", t, B, &t_dev));
     API_TRY(e, upload_ints(e, "api#y", y_host, B, &y_dev));
     API_TRY(e, e->ws.getT("loop#out6", (size_t)B * e->net.desc.out_channels * H * W, &out6));
     PSampleCoef cf{c->c1, c->c2, c->pc1, c->pc2, c->min_log, c->max_log, t != 0 ? 1.0f : 0.0f, c->ddim, c->sa_prev, c->s1m_prev};
