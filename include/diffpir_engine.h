@@ -115,7 +115,10 @@ int dpir_load_unet(dpir_engine* e, const dpir_unet_desc* desc, const dpir_tensor
 int dpir_set_precision(dpir_engine* e, int mode);
 
 /* Replaces UNetModel.forward (guided_diffusion/unet.py:634-663): x_dev [B,3,H,W], t_host [B] int64
- * timesteps (host), y_host [B] int64 labels or NULL -> out_dev [B,out_channels,H,W]. */
+ * timesteps (host), y_host [B] int64 labels or NULL -> out_dev [B,out_channels,H,W].  Asynchronous on the engine stream.  When all B timesteps
+ * are equal and there are no labels (what utils_model.model_fn always passes: `[t_step] * x.shape[0]`) the timestep is written on the device by a
+ * kernel (no host copy, no synchronisation) and the time embedding + FiLM projection are evaluated for one row and shared; otherwise t / y are
+ * uploaded (one stream synchronisation). */
 int dpir_unet_forward(dpir_engine* e, const float* x_dev, const int64_t* t_host, const int64_t* y_host,
                       float* out_dev, int B, int H, int W);
 
