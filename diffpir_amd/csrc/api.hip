@@ -51,7 +51,21 @@ static int read_range(dpir_engine* e, unsigned long long* n) {
         return fail(e, Status{DPIR_ERR_HIP, "reading the operand range counter failed"});
     return DPIR_OK;
 }
+// fft3.hip: a dependency wait of the single-launch prox gave up (bounded spin).  Cannot happen by construction (a job's dependencies are held by
+// running workgroups); if it does, the images are wrong: sticky until the engine is destroyed, and the engine falls back to the three launches.
+static int check_prox_err(dpir_engine* e) {
+    if (!e->prox_err || !e->prox_fused_pending) return DPIR_OK;
+    unsigned v = 0;
+    if (hipMemcpyAsync(&v, e->prox_err, sizeof(v), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
+        return fail(e, Status{DPIR_ERR_HIP, "reading the prox error word failed"});
+    if (v == 0) { e->prox_fused_pending = false; return DPIR_OK; }
+    e->prox_mode = 0;
+    e->invalidate_graphs();
+    return fail(e, Status{DPIR_ERR_HIP, "the single-launch FFT prox (fft3.hip) gave up waiting for a dependency (code " + std::to_string(v) +
+                                        "): results since the last synchronisation are invalid; the engine now uses the three-launch path"});
+}
 int dpir_check_range(dpir_engine* e) {
+    if (int rc = check_prox_err(e)) return rc;
     if (!e->range_ctr || e->precision == 0) { e->fwd_since_sync = 0; e->replay_last = nullptr; return DPIR_OK; }
     unsigned long long n = 0;
     if (int rc = read_range(e, &n)) return rc;
@@ -117,12 +131,13 @@ Status dpir_engine::fft2_table(int N, const float2** out) {
     return Status{};
 }
 
-Status dpir_engine::fft2_map(int N, int sf, const Fft2Map** out) {
-    auto key = std::make_pair(N, sf);
+Status dpir_engine::fft2_map(int N, int sf, const Fft2Map** out, bool colmajor) {
+    auto key = std::make_pair(N, sf + (colmajor ? 16 : 0));
     auto it = fft2_maps.find(key);
     if (it == fft2_maps.end()) {
         Fft2Map m;
-        fft2_build_map(N, sf, m.h_slot_col, m.h_col_slot);
+        if (colmajor) fft4_build_map(N, sf, m.h_slot_col, m.h_col_slot);
+        else fft2_build_map(N, sf, m.h_slot_col, m.h_col_slot);
         DPIR_HIP(hipMalloc((void**)&m.slot_col, m.h_slot_col.size() * sizeof(int)));
         DPIR_HIP(hipMalloc((void**)&m.col_slot, m.h_col_slot.size() * sizeof(int)));
         DPIR_HIP(hipMemcpy(m.slot_col, m.h_slot_col.data(), m.h_slot_col.size() * sizeof(int), hipMemcpyHostToDevice));
@@ -188,8 +203,11 @@ int dpir_create(int device, dpir_engine** out) {
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DPIR_ERR_HIP; }
     e->prof.stream = e->stream;
-    if (hipMalloc((void**)&e->range_ctr, sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(e->range_ctr, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
+    if (hipMalloc((void**)&e->range_ctr, 2 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(e->range_ctr, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
+    e->prox_err = reinterpret_cast<unsigned*>(e->range_ctr + 1);
+    e->cus = prop.multiProcessorCount;
+    if (const char* ev = getenv("DPIR_PROX_MODE")) { const int m = atoi(ev); if (m >= 0 && m <= 2) e->prox_mode = m; }
     *out = e;
     return DPIR_OK;
 }
@@ -399,6 +417,23 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
         DPIR_TRY(e->ws.getT("prox#psf", (size_t)B * H * W, &psf));
         SolveArgs none{};
         DPIR_TRY(launch_psf_embed_real(s, k, kh, kw, psf, B, H, W));
+        if (st->colmajor) {      // wave-per-transform kernels, column-major spectra (fft4.hip)
+            const int NC = st->WP;
+            DPIR_TRY(launch_rfft4_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, NC, nullptr, 0, st->slot_col));
+            DPIR_TRY(launch_cfft4_cols(s, tw, st->FB, none, false, B, NC));
+            const float* ysrc4 = y;
+            if (sf > 1) {
+                float* yup = nullptr;
+                DPIR_TRY(e->ws.getT("prox#yup", (size_t)B * 3 * H * W, &yup));
+                DPIR_TRY(launch_upsample_real(s, y, sf, yup, B * 3, H / sf, W / sf));
+                ysrc4 = yup;
+            }
+            DPIR_TRY(launch_rfft4_rows(s, tw, ysrc4, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, NC, nullptr, 0, st->slot_col));
+            DPIR_TRY(launch_cfft4_cols(s, tw, st->FBFy, none, false, B * 3, NC));
+            DPIR_TRY(launch_precalc_finish2(s, st->FB, st->FBFy, st->F2B, B, (size_t)H * NC));
+            if (sf > 1) DPIR_TRY(launch_fold_f2b4(s, st->F2B, st->slot_col, NC, sf, st->invW, B));
+            return Status{};
+        }
         DPIR_TRY(launch_rfft_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, W, nullptr, 0, st->slot_col));
         DPIR_TRY(launch_cfft_cols(s, tw, st->FB, none, false, B, H));
         const float* ysrc = y;
@@ -430,7 +465,8 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
 static Status prox_alloc(dpir_engine* e, int sf, int B, int H, int W, ProxState* st) {
     st->B = B; st->H = H; st->W = W; st->sf = sf;
     st->half = fft2_supported(H, W, sf);
-    st->WP = st->half ? fft2_padded_width(W) : W;
+    st->colmajor = e->prox_mode == 2 && fft4_supported(H, W, sf);
+    st->WP = st->colmajor ? fft4_columns(W, sf) : (st->half ? fft2_padded_width(W) : W);
     size_t hw = (size_t)H * st->WP;
     if (hipMalloc((void**)&st->FB, B * hw * sizeof(float2)) != hipSuccess ||
         hipMalloc((void**)&st->F2B, B * hw * sizeof(float)) != hipSuccess ||
@@ -439,7 +475,7 @@ static Status prox_alloc(dpir_engine* e, int sf, int B, int H, int W, ProxState*
     st->invW = nullptr; st->slot_col = nullptr; st->col_slot = nullptr; st->h_col_slot = nullptr;
     if (st->half && sf > 1) {
         const dpir_engine::Fft2Map* m = nullptr;
-        DPIR_TRY(e->fft2_map(W, sf, &m));
+        DPIR_TRY(e->fft2_map(W, sf, &m, st->colmajor));
         st->slot_col = m->slot_col; st->col_slot = m->col_slot; st->h_col_slot = &m->h_col_slot;
         if (hipMalloc((void**)&st->invW, (size_t)B * (H / sf) * (W / sf / 2 + 1) * sizeof(float)) != hipSuccess)
             return Status{DPIR_ERR_NOMEM, "pre_calculate: hipMalloc failed"};
@@ -500,7 +536,7 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
                     bool mir = v > st.W / 2;
                     int su = mir ? (st.H - u) % st.H : u, sv = mir ? st.W - v : v;
                     if (st.h_col_slot) sv = (*st.h_col_slot)[sv];           // sf > 1: alias-grouped column order
-                    const char* sp = tmp.data() + (pl * shw + (size_t)su * st.WP + sv) * esz;
+                    const char* sp = tmp.data() + (pl * shw + (st.colmajor ? (size_t)sv * st.H + su : (size_t)su * st.WP + sv)) * esz;
                     char* dp = reinterpret_cast<char*>(host_dst) + (pl * hw + (size_t)u * st.W + v) * esz;
                     memcpy(dp, sp, esz);
                     if (mir && which != 1) reinterpret_cast<float*>(dp)[1] = -reinterpret_cast<float*>(dp)[1];
@@ -525,6 +561,35 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
     return DPIR_OK;
 }
 
+// The half-spectrum prox passes described by `a` (rows forward -> columns with the solve -> rows inverse): ONE persistent launch (fft3.hip) where
+// the size allows it, the three launches of fft2.hip otherwise (N = 64, DPIR_PROX_FUSED=0).  Same bodies, same bits.
+static Status prox_passes(dpir_engine* e, const ProxState& st, ProxFusedArgs a) {
+    hipStream_t s = e->stream;
+    const int P = st.B * 3, N = st.W;
+    a.P = P; a.WP = st.WP;
+    if (st.colmajor) {
+        DPIR_TRY(launch_rfft4_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, st.WP, a.fu.eps6, a.fu.out_ch, a.slot_col));
+        DPIR_TRY(launch_cfft4_cols(s, a.tw, a.hbuf, a.solve, true, P, st.WP));
+        const RenoiseArgs ra4{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
+        return launch_irfft4_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, st.WP, a.rn.xt ? &ra4 : nullptr, a.col_slot);
+    }
+    if (e->prox_mode == 1 && prox_fused_supported(st.H, st.W, st.sf)) {
+        a.K = prox_fused_round(P);
+        a.nr_max = (P + a.K - 1) / a.K + 12;
+        const size_t words = prox_fused_sync_words(P, a.K);
+        const uint64_t gen = e->ws.generation;
+        DPIR_TRY(e->ws.getT("prox#sync", words, &a.sync));
+        if (e->ws.generation != gen) DPIR_HIP(hipMemsetAsync(a.sync, 0, words * sizeof(unsigned), s));      // fresh buffer; afterwards the kernel cleans up
+        a.err = e->prox_err;
+        e->prox_fused_pending = true;
+        return launch_prox_fused(s, a, N, st.sf, e->cus);
+    }
+    DPIR_TRY(launch_rfft_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, N, a.fu.eps6, a.fu.out_ch, a.slot_col));
+    DPIR_TRY(launch_cfft_cols(s, a.tw, a.hbuf, a.solve, true, P, st.H));
+    const RenoiseArgs ra{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
+    return launch_irfft_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, N, a.rn.xt ? &ra : nullptr, a.col_slot);
+}
+
 // out = blend ? base + g*((ifft)*oa+ob - base) : (ifft)*oa+ob ; input pre-map v = (x*pa+pb)*alpha
 static Status data_solution_impl(dpir_engine* e, const ProxState& st, const float* x, float pa, float pb, float alpha, float* out,
                                  float oa, float ob, const float* blend_base, float g, const StepDev* sp = nullptr) {
@@ -534,15 +599,15 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
         DPIR_TRY(e->fft2_table(st.W, &tw));
         float2* hbuf = nullptr;
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)st.B * 3 * st.H * st.WP, &hbuf));
-        hipStream_t s2 = e->stream;
         ProfScope ps2(&e->prof, PC_FFT);
-        DPIR_TRY(launch_rfft_rows(s2, tw, x, pa, pb, alpha, sp, hbuf, st.B * 3, st.W, nullptr, 0, st.slot_col));
-        SolveArgs a2{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp, st.invW, st.slot_col};
-        DPIR_TRY(launch_cfft_cols(s2, tw, hbuf, a2, true, st.B * 3, st.H));
-        float sc = 1.0f / ((float)st.H * (float)st.W);
-        DPIR_TRY(launch_irfft_rows(s2, tw, hbuf, out, sc, oa, ob, (blend_base && g != 1.0f) ? blend_base : nullptr, g, st.B * 3, st.W, nullptr,
-                                   st.col_slot));
-        return Status{};
+        ProxFusedArgs a{};
+        a.x = x; a.pa = pa; a.pb = pb; a.pm = alpha; a.sp = sp; a.fu = RowsFuse{nullptr, 0}; a.slot_col = st.slot_col;
+        a.solve = SolveArgs{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp, st.invW, st.slot_col};
+        a.out = out; a.scale = 1.0f / ((float)st.H * (float)st.W); a.oa = oa; a.ob = ob;
+        a.blend_base = (blend_base && g != 1.0f) ? blend_base : nullptr; a.g = g;
+        a.rn = RenoiseFuse{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0}; a.col_slot = st.col_slot;
+        a.hbuf = hbuf; a.tw = tw;
+        return prox_passes(e, st, a);
     }
     FftPlan ph, pw;
     DPIR_TRY(e->fft_plan(st.H, &ph));
@@ -559,6 +624,13 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
     return Status{};
 }
 
+int dpir_set_prox_launch(dpir_engine* e, int mode) {
+    if (!e || mode < 0 || mode > 2) return fail(e, invalid("dpir_set_prox_launch: mode must be 0, 1 or 2"));
+    (void)hipSetDevice(e->device);
+    if (mode != e->prox_mode) { (void)hipStreamSynchronize(e->stream); e->invalidate_graphs(); }
+    e->prox_mode = mode;
+    return DPIR_OK;
+}
 int dpir_data_solution(dpir_engine* e, const dpir_prox* p, const float* x, float alpha, float* out) {
     if (!e || !p || !x || !out) return fail(e, invalid("dpir_data_solution: null argument"));
     (void)hipSetDevice(e->device);
@@ -569,6 +641,50 @@ int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0, float tau
     if (!e || !p || !x0) return fail(e, invalid("dpir_prox_fft_apply: null argument"));
     (void)hipSetDevice(e->device);
     API_TRY(e, data_solution_impl(e, p->st, x0, 0.5f, 0.5f, tau, x0, 2.f, -1.f, x0, guidance));
+    return DPIR_OK;
+}
+
+// measurement: n back-to-back applies between two events on the engine stream, eagerly or as ONE captured graph (what the restoration
+// loop replays: no host launch cost, no per-apply event records) -> device microseconds per apply, launch boundaries included
+int dpir_prox_fft_apply_timed(dpir_engine* e, const dpir_prox* p, float* x0, float tau, float guidance, int n, int use_graph, float* us_per_apply) {
+    if (!e || !p || !x0 || !us_per_apply || n < 1) return fail(e, invalid("dpir_prox_fft_apply_timed: bad argument"));
+    (void)hipSetDevice(e->device);
+    API_TRY(e, data_solution_impl(e, p->st, x0, 0.5f, 0.5f, tau, x0, 2.f, -1.f, x0, guidance));       // allocates the workspace, warms the code
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    API_HIP(e, hipEventCreate(&ev0));
+    API_HIP(e, hipEventCreate(&ev1));
+    hipGraphExec_t exec = nullptr;
+    Status st;
+    const bool prof_on = e->prof.on;
+    e->prof.on = false;
+    if (use_graph) {
+        hipGraph_t graph = nullptr;
+        e->ws.frozen = true;
+        hipError_t herr = hipStreamBeginCapture(e->stream, hipStreamCaptureModeThreadLocal);
+        if (herr != hipSuccess) st = Status{DPIR_ERR_HIP, std::string("hipStreamBeginCapture: ") + hipGetErrorString(herr)};
+        else {
+            for (int i = 0; i < n && st.ok(); ++i) st = data_solution_impl(e, p->st, x0, 0.5f, 0.5f, tau, x0, 2.f, -1.f, x0, guidance);
+            herr = hipStreamEndCapture(e->stream, &graph);
+            if (st.ok() && herr != hipSuccess) st = Status{DPIR_ERR_HIP, std::string("hipStreamEndCapture: ") + hipGetErrorString(herr)};
+        }
+        e->ws.frozen = false;
+        if (st.ok() && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) != hipSuccess) st = Status{DPIR_ERR_HIP, "hipGraphInstantiate failed"};
+        if (graph) (void)hipGraphDestroy(graph);
+        if (st.ok() && hipGraphLaunch(exec, e->stream) != hipSuccess) st = Status{DPIR_ERR_HIP, "hipGraphLaunch failed"};      // warm-up replay
+    }
+    if (st.ok()) {
+        (void)hipEventRecord(ev0, e->stream);
+        if (use_graph) { if (hipGraphLaunch(exec, e->stream) != hipSuccess) st = Status{DPIR_ERR_HIP, "hipGraphLaunch failed"}; }
+        else for (int i = 0; i < n && st.ok(); ++i) st = data_solution_impl(e, p->st, x0, 0.5f, 0.5f, tau, x0, 2.f, -1.f, x0, guidance);
+        (void)hipEventRecord(ev1, e->stream);
+        if (hipEventSynchronize(ev1) != hipSuccess) st = Status{DPIR_ERR_HIP, "hipEventSynchronize failed"};
+        float ms = 0.f;
+        if (st.ok() && hipEventElapsedTime(&ms, ev0, ev1) == hipSuccess) *us_per_apply = ms * 1e3f / (float)n;
+    }
+    e->prof.on = prof_on;
+    if (exec) (void)hipGraphExecDestroy(exec);
+    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
+    API_TRY(e, st);
     return DPIR_OK;
 }
 
@@ -801,11 +917,13 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         float2* hbuf = nullptr;
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)prox->B * 3 * prox->H * prox->WP, &hbuf));
         ProfScope ps(&e->prof, PC_FFT);
-        DPIR_TRY(launch_rfft_rows(s, tw, b.x, 0.5f, 0.5f, 1.f, b.cur, hbuf, B * 3, W, b.out6, e->net.desc.out_channels, prox->slot_col));
-        SolveArgs sa{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur, prox->invW, prox->slot_col};
-        DPIR_TRY(launch_cfft_cols(s, tw, hbuf, sa, true, B * 3, H));
-        RenoiseArgs ra{b.x, b.cur, b.lp, d.noise_n1_dev, d.noise_n2_dev, d.noise_n2_dev ? total : 0, with_n1 ? 1 : 0};
-        DPIR_TRY(launch_irfft_rows(s, tw, hbuf, b.x0, 1.0f / ((float)H * (float)W), 2.f, -1.f, nullptr, 1.f, B * 3, W, &ra, prox->col_slot));
+        ProxFusedArgs a{};
+        a.x = b.x; a.pa = 0.5f; a.pb = 0.5f; a.pm = 1.f; a.sp = b.cur; a.fu = RowsFuse{b.out6, e->net.desc.out_channels}; a.slot_col = prox->slot_col;
+        a.solve = SolveArgs{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur, prox->invW, prox->slot_col};
+        a.out = b.x0; a.scale = 1.0f / ((float)H * (float)W); a.oa = 2.f; a.ob = -1.f; a.blend_base = nullptr; a.g = 1.f;
+        a.rn = RenoiseFuse{b.x, b.cur, b.lp, d.noise_n1_dev, d.noise_n2_dev, d.noise_n2_dev ? total : 0, with_n1 ? 1 : 0}; a.col_slot = prox->col_slot;
+        a.hbuf = hbuf; a.tw = tw;
+        DPIR_TRY(prox_passes(e, *prox, a));
         DPIR_HIP(hipGetLastError());
         return Status{};
     }
@@ -916,7 +1034,8 @@ static int run_loop_once(dpir_engine* e, const dpir_loop_desc* dd, const dpir_st
     bool need_prox = d.task == DPIR_TASK_DEBLUR || d.task == DPIR_TASK_SR_BLUR;
     ProxState& prox = e->loop_prox;
     // sf decides the spectrum layout (half-spectrum register FFT vs bit-reversed c2c): a change of sf re-allocates too
-    if (need_prox && (prox.B != B || prox.H != H || prox.W != W || prox.sf != d.sf || prox.half != fft2_supported(H, W, d.sf) || !prox.FB)) {
+    if (need_prox && (prox.B != B || prox.H != H || prox.W != W || prox.sf != d.sf || prox.half != fft2_supported(H, W, d.sf) ||
+                      prox.colmajor != (e->prox_mode == 2 && fft4_supported(H, W, d.sf)) || !prox.FB)) {
         API_HIP(e, hipStreamSynchronize(e->stream));
         prox_release(&prox);
         e->invalidate_graphs();

@@ -80,7 +80,8 @@ struct ProxState {   // dpir_prox
     int B = 0, H = 0, W = 0, sf = 1;
     float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
     bool half = false;     // true: half spectrum [.., H, WP] (fft2.hip; columns alias-grouped when sf > 1); false: bit-reversed full c2c (fft.hip)
-    int WP = 0;            // stored row length (complex elements)
+    bool colmajor = false; // half spectrum stored COLUMN-major [.., WP slots, H] for the wave-per-transform kernels (fft4.hip, 256 x 256)
+    int WP = 0;            // stored row length (complex elements); colmajor: stored columns (slots) per plane
     float* invW = nullptr; // half && sf > 1: alias mean of F2B [B][H/sf][W/sf/2+1]
     const int* slot_col = nullptr; const int* col_slot = nullptr;     // half && sf > 1: device slot maps (engine-owned, fft2_map)
     const std::vector<int>* h_col_slot = nullptr;                     // host copy (dpir_prox_read)
@@ -103,7 +104,7 @@ struct dpir_engine {
     std::map<int, dpir::FftPlan> fft_plans;
     std::map<int, float2*> fft2_tw;              // W_N^m tables (N entries) for fft2.hip
     struct Fft2Map { int* slot_col = nullptr; int* col_slot = nullptr; std::vector<int> h_slot_col, h_col_slot; };
-    std::map<std::pair<int, int>, Fft2Map> fft2_maps;   // (N, sf) -> alias-grouped column permutation of the half-spectrum layout
+    std::map<std::pair<int, int>, Fft2Map> fft2_maps;   // (N, sf [+ 16 for the column-major layout]) -> alias-grouped column permutation of the half-spectrum layout
     std::map<std::pair<int, int>, dpir::ResizerTab> resizers;   // (in_len, sf)
     std::vector<void*> user_allocs;
     bool collect_taps = true;
@@ -133,6 +134,11 @@ struct dpir_engine {
         graphs.clear();
     }
     unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
+    // fft3.hip, the single-launch FFT prox: device error word (a bounded dependency wait gave up), set when a fused launch has been issued
+    // since the last check, CU count of the device, on / off (DPIR_PROX_FUSED=0: the three launches of fft2.hip)
+    // prox_mode (dpir_set_prox_launch): 2 = wave-per-transform kernels on a column-major spectrum (fft4.hip; 256 x 256, the default), 1 = fft2's bodies as
+    // one persistent launch (fft3.hip), 0 = fft2's three launches; sizes a mode does not cover fall back to 0
+    unsigned* prox_err = nullptr; bool prox_fused_pending = false; int cus = 256; int prox_mode = 2;
     // conv7's fused hop (Conv6Emit) is an inter-workgroup wait; when it times out (the GPU is shared with other engines / processes) the
     // engine does not fail: it switches the hop off for its lifetime and re-runs what the time-out invalidated -- the restoration loop
     // (dpir_run_loop) or the ONE eager forward issued since the last synchronisation (replay_last); see dpir_check_range
@@ -143,7 +149,7 @@ struct dpir_engine {
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);
     dpir::Status fft2_table(int N, const float2** out);
-    dpir::Status fft2_map(int N, int sf, const Fft2Map** out);
+    dpir::Status fft2_map(int N, int sf, const Fft2Map** out, bool colmajor = false);
     dpir::Status resizer(int in_len, int sf, dpir::ResizerTab* out);
 };
 

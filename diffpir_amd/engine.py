@@ -164,6 +164,12 @@ class Engine:
 
     precision = "f32"
 
+    def set_prox_launch(self, mode):
+        """'wave' / 2: wave-per-transform kernels on a column-major spectrum (csrc/fft4.hip, 256 x 256; default); 'fused' / 1: fft2's passes as one
+        persistent launch (csrc/fft3.hip); 'launches' / 0: fft2's three launches.  Takes effect at the next pre_calculate / loop call."""
+        m = {"wave": 2, "fused": 1, "launches": 0}.get(mode, mode)
+        self._check(self.lib.dpir_set_prox_launch(self.h, int(m)))
+
     def enable_grad(self, on=True):
         """Gradient mode (generate_mode 'DPS_y0'): before load_unet / load_state_dict."""
         self._check(self.lib.dpir_enable_grad(self.h, 1 if on else 0))

@@ -147,6 +147,18 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
 int dpir_data_solution(dpir_engine* e, const dpir_prox* p, const float* x_dev, float alpha, float* out_dev);
 /* Replaces main_ddpir.py:395-400: x0 <- x0 + g*(2*data_solution(x0/2+.5, tau) - 1 - x0), in place. */
 int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0_dev, float tau, float guidance);
+/* Measurement helper (bench.py `roofline_prox`): dpir_prox_fft_apply n times back to back between two HIP events on the engine stream -- eager launches
+ * (use_graph 0) or ONE captured graph of the n applies (use_graph 1: how dpir_run_loop replays the step; no host launch cost, no event record between
+ * applies) -> device microseconds per apply, launch boundaries included.  x0 is overwritten n + 1 (+ n) times. */
+int dpir_prox_fft_apply_timed(dpir_engine* e, const dpir_prox* p, float* x0_dev, float tau, float guidance, int n, int use_graph, float* us_per_apply);
+/* How the half-spectrum data_solution (utils/utils_sisr.py:65-75; 256^2 / 512^2, sf 1 / 2 / 4) is launched.  mode 1 (default; env DPIR_PROX_FUSED=0
+ * selects 0 at dpir_create): ONE persistent launch -- per-plane ticketed row / column / inverse-row jobs, each plane's half-spectrum intermediate kept in
+ * the L2 of the XCD that claimed the plane (csrc/fft3.hip).  mode 0: three dependent launches (csrc/fft2.hip).  Both run the same device bodies and
+ * return the same bits; other sizes always use the launches.  A bounded dependency wait that gives up in mode 1 (cannot happen by construction)
+ * is reported as DPIR_ERR_HIP by the next dpir_sync / dpir_d2h and switches the engine to mode 0.  Drops the captured step graphs.
+ * mode 2 (256 x 256): one wave per 256-point transform on a column-major half spectrum (csrc/fft4.hip).  A dpir_prox keeps the layout of the mode it
+ * was created in. */
+int dpir_set_prox_launch(dpir_engine* e, int mode);
 /* Replaces main_ddpir.py:392-394: x0_p = (m*(2y-1)+tau*x0)/(m+tau); x0 += g*(x0_p-x0).  mask u8 [B,3,H,W]. */
 int dpir_prox_mask(dpir_engine* e, float* x0_dev, const float* y_dev, const uint8_t* mask_dev,
                    float tau, float guidance, int B, int H, int W);
