@@ -3,6 +3,7 @@
 // the header; this file only validates, dispatches to the launchers and keeps the error string.
 #include "engine.h"
 #include "grad.h"
+#include "fft4_wave.h"
 #include <math.h>
 #include <string.h>
 #include <stdlib.h>
@@ -51,21 +52,7 @@ static int read_range(dpir_engine* e, unsigned long long* n) {
         return fail(e, Status{DPIR_ERR_HIP, "reading the operand range counter failed"});
     return DPIR_OK;
 }
-// fft3.hip: a dependency wait of the single-launch prox gave up (bounded spin).  Cannot happen by construction (a job's dependencies are held by
-// running workgroups); if it does, the images are wrong: sticky until the engine is destroyed, and the engine falls back to the three launches.
-static int check_prox_err(dpir_engine* e) {
-    if (!e->prox_err || !e->prox_fused_pending) return DPIR_OK;
-    unsigned v = 0;
-    if (hipMemcpyAsync(&v, e->prox_err, sizeof(v), hipMemcpyDeviceToHost, e->stream) != hipSuccess || hipStreamSynchronize(e->stream) != hipSuccess)
-        return fail(e, Status{DPIR_ERR_HIP, "reading the prox error word failed"});
-    if (v == 0) { e->prox_fused_pending = false; return DPIR_OK; }
-    e->prox_mode = 0;
-    e->invalidate_graphs();
-    return fail(e, Status{DPIR_ERR_HIP, "the single-launch FFT prox (fft3.hip) gave up waiting for a dependency (code " + std::to_string(v) +
-                                        "): results since the last synchronisation are invalid; the engine now uses the three-launch path"});
-}
 int dpir_check_range(dpir_engine* e) {
-    if (int rc = check_prox_err(e)) return rc;
     if (!e->range_ctr || e->precision == 0) { e->fwd_since_sync = 0; e->replay_last = nullptr; return DPIR_OK; }
     unsigned long long n = 0;
     if (int rc = read_range(e, &n)) return rc;
@@ -74,9 +61,13 @@ int dpir_check_range(dpir_engine* e) {
         // caller-owned and untouched) on the unfused path; a burst of several cannot be re-issued from here
         const int burst = e->fwd_since_sync;
         std::function<int()> replay = std::move(e->replay_last);
+        // work enqueued BEHIND the forward (finalize, a prox step, a copy) has consumed its invalid output: re-issuing the forward alone would leave
+        // that work wrong (or overwrite what it wrote in place) -- only a forward that is still the last thing on the stream is replayed
+        const bool trailing = e->enqueue_serial() != e->replay_serial;
         e->fwd_since_sync = 0; e->replay_last = nullptr;
-        if (burst != 1 || !replay)
+        if (burst != 1 || !replay || trailing)
             return fail(e, Status{DPIR_ERR_HIP, "conv7 fused emission timed out " + (burst == 0 ? std::string("inside a loop call (dpir_run_dps_loop)") :
+                                                burst == 1 ? std::string("in a forward that other work was already queued behind (or whose buffers were freed)") :
                                                 "during a burst of " + std::to_string(burst) + " un-synchronised forwards") + ": the results since the last "
                                                 "synchronisation are invalid.  The hop is now off for this engine; re-issue the call(s) (not a sticky error)"});
         if (int rc = replay()) return rc;
@@ -91,8 +82,11 @@ int dpir_check_range(dpir_engine* e) {
 }
 static int check_range(dpir_engine* e) { return dpir_check_range(e); }
 // a new forward / loop starts a new accounting period (stream-ordered)
+// Only the range count (bits 0..39) restarts: the fused-hop time-out count above it stays until dpir_check_range has seen it, so a time-out in an
+// EARLIER forward of an un-synchronised burst is not wiped by the next forward's clear.
+__global__ void range_clear_kernel(unsigned long long* ctr) { *ctr &= ~((1ull << 40) - 1ull); }
 static void range_clear(dpir_engine* e) {
-    if (e->range_ctr && e->precision != 0) (void)hipMemsetAsync(e->range_ctr, 0, sizeof(unsigned long long), e->stream);
+    if (e->range_ctr && e->precision != 0) hipLaunchKernelGGL(range_clear_kernel, dim3(1), dim3(1), 0, e->stream, e->range_ctr);
 }
 static int ilog2u(int v) { int l = 0; while ((1 << l) < v) ++l; return l; }
 
@@ -123,6 +117,7 @@ Status dpir_engine::fft2_table(int N, const float2** out) {
         double a = -2.0 * M_PI * (double)m / (double)N;
         tw[m] = make_float2((float)cos(a), (float)sin(a));
     }
+    if (N == 256) { tw.resize(WAVE_TW_OFFSET + WAVE_TW_COUNT); wave_tw_fill(tw.data(), tw.data() + WAVE_TW_OFFSET); }   // fft4_wave.h: per-lane constants
     void* d = nullptr;
     DPIR_HIP(hipMalloc(&d, tw.size() * sizeof(float2)));
     DPIR_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -203,11 +198,10 @@ int dpir_create(int device, dpir_engine** out) {
     e->device = device;
     if (hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking) != hipSuccess) { delete e; return DPIR_ERR_HIP; }
     e->prof.stream = e->stream;
-    if (hipMalloc((void**)&e->range_ctr, 2 * sizeof(unsigned long long)) != hipSuccess ||
-        hipMemset(e->range_ctr, 0, 2 * sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
-    e->prox_err = reinterpret_cast<unsigned*>(e->range_ctr + 1);
+    if (hipMalloc((void**)&e->range_ctr, sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(e->range_ctr, 0, sizeof(unsigned long long)) != hipSuccess) { (void)hipStreamDestroy(e->stream); delete e; return DPIR_ERR_NOMEM; }
     e->cus = prop.multiProcessorCount;
-    if (const char* ev = getenv("DPIR_PROX_MODE")) { const int m = atoi(ev); if (m >= 0 && m <= 2) e->prox_mode = m; }
+    if (const char* ev = getenv("DPIR_PROX_MODE")) { const int m = atoi(ev); if (m == 0 || m == 1) e->prox_mode = m; }
     *out = e;
     return DPIR_OK;
 }
@@ -254,6 +248,7 @@ int dpir_free(dpir_engine* e, void* dev) {
     for (size_t i = 0; i < e->user_allocs.size(); ++i)
         if (e->user_allocs[i] == dev) {
             (void)hipStreamSynchronize(e->stream);
+            ++e->copy_serial;                      // a pending forward replay may hold this pointer: it is no longer valid (dpir_check_range)
             (void)hipFree(dev);
             e->user_allocs.erase(e->user_allocs.begin() + i);
             return DPIR_OK;
@@ -262,6 +257,7 @@ int dpir_free(dpir_engine* e, void* dev) {
 }
 int dpir_h2d(dpir_engine* e, void* d, const void* h, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;
+    ++e->copy_serial;
     API_HIP(e, hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, e->stream));
     API_HIP(e, hipStreamSynchronize(e->stream));   // the host buffer may be pageable / short-lived
     return DPIR_OK;
@@ -276,6 +272,7 @@ int dpir_d2h(dpir_engine* e, void* h, const void* d, size_t bytes) {
 }
 int dpir_d2d(dpir_engine* e, void* dd, const void* ds, size_t bytes) {
     if (!e) return DPIR_ERR_INVALID;
+    ++e->copy_serial;
     API_HIP(e, hipMemcpyAsync(dd, ds, bytes, hipMemcpyDeviceToDevice, e->stream));
     return DPIR_OK;
 }
@@ -339,8 +336,8 @@ int dpir_unet_forward(dpir_engine* e, const float* x, const int64_t* t_host, con
     if (!e->fuse_h1_off && !e->grad_enabled && e->precision != 0) {
         std::vector<int64_t> tv(t_host, t_host + B), yv;
         if (y_host) yv.assign(y_host, y_host + B);
-        ++e->fwd_since_sync;
-        e->replay_last = [=]() { return dpir_unet_forward(e, x, tv.data(), yv.empty() ? nullptr : yv.data(), out, B, H, W); };
+        if (x != out) e->arm_replay([=]() { return dpir_unet_forward(e, x, tv.data(), yv.empty() ? nullptr : yv.data(), out, B, H, W); });
+        else { ++e->fwd_since_sync; e->replay_last = nullptr; }         // in place: the input is gone, nothing to re-issue from
     }
     return DPIR_OK;
 }
@@ -361,8 +358,8 @@ int dpir_model_fn_xstart(dpir_engine* e, const float* x, int t, float c1, float 
     if (!e->fuse_h1_off && !e->grad_enabled && e->precision != 0) {
         std::vector<int64_t> yv;
         if (y_host) yv.assign(y_host, y_host + B);
-        ++e->fwd_since_sync;
-        e->replay_last = [=]() { return dpir_model_fn_xstart(e, x, t, c1, c2, yv.empty() ? nullptr : yv.data(), x0, B, H, W); };
+        if (x != x0) e->arm_replay([=]() { return dpir_model_fn_xstart(e, x, t, c1, c2, yv.empty() ? nullptr : yv.data(), x0, B, H, W); });
+        else { ++e->fwd_since_sync; e->replay_last = nullptr; }
     }
     return DPIR_OK;
 }
@@ -420,7 +417,7 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
         if (st->colmajor) {      // wave-per-transform kernels, column-major spectra (fft4.hip)
             const int NC = st->WP;
             DPIR_TRY(launch_rfft4_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, NC, nullptr, 0, st->slot_col));
-            DPIR_TRY(launch_cfft4_cols(s, tw, st->FB, none, false, B, NC));
+            DPIR_TRY(launch_cfft4_cols(s, tw, st->FB, none, false, B, NC, e->cus));
             const float* ysrc4 = y;
             if (sf > 1) {
                 float* yup = nullptr;
@@ -429,7 +426,7 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
                 ysrc4 = yup;
             }
             DPIR_TRY(launch_rfft4_rows(s, tw, ysrc4, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, NC, nullptr, 0, st->slot_col));
-            DPIR_TRY(launch_cfft4_cols(s, tw, st->FBFy, none, false, B * 3, NC));
+            DPIR_TRY(launch_cfft4_cols(s, tw, st->FBFy, none, false, B * 3, NC, e->cus));
             DPIR_TRY(launch_precalc_finish2(s, st->FB, st->FBFy, st->F2B, B, (size_t)H * NC));
             if (sf > 1) DPIR_TRY(launch_fold_f2b4(s, st->F2B, st->slot_col, NC, sf, st->invW, B));
             return Status{};
@@ -465,7 +462,7 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
 static Status prox_alloc(dpir_engine* e, int sf, int B, int H, int W, ProxState* st) {
     st->B = B; st->H = H; st->W = W; st->sf = sf;
     st->half = fft2_supported(H, W, sf);
-    st->colmajor = e->prox_mode == 2 && fft4_supported(H, W, sf);
+    st->colmajor = e->prox_mode == 1 && fft4_supported(H, W, sf);
     st->WP = st->colmajor ? fft4_columns(W, sf) : (st->half ? fft2_padded_width(W) : W);
     size_t hw = (size_t)H * st->WP;
     if (hipMalloc((void**)&st->FB, B * hw * sizeof(float2)) != hipSuccess ||
@@ -536,7 +533,7 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
                     bool mir = v > st.W / 2;
                     int su = mir ? (st.H - u) % st.H : u, sv = mir ? st.W - v : v;
                     if (st.h_col_slot) sv = (*st.h_col_slot)[sv];           // sf > 1: alias-grouped column order
-                    const char* sp = tmp.data() + (pl * shw + (st.colmajor ? (size_t)sv * st.H + su : (size_t)su * st.WP + sv)) * esz;
+                    const char* sp = tmp.data() + (pl * shw + (st.colmajor ? (size_t)sv * st.H + fft4_row_pos(su) : (size_t)su * st.WP + sv)) * esz;
                     char* dp = reinterpret_cast<char*>(host_dst) + (pl * hw + (size_t)u * st.W + v) * esz;
                     memcpy(dp, sp, esz);
                     if (mir && which != 1) reinterpret_cast<float*>(dp)[1] = -reinterpret_cast<float*>(dp)[1];
@@ -561,32 +558,19 @@ int dpir_prox_read(dpir_engine* e, const dpir_prox* p, int which, void* host_dst
     return DPIR_OK;
 }
 
-// The half-spectrum prox passes described by `a` (rows forward -> columns with the solve -> rows inverse): ONE persistent launch (fft3.hip) where
-// the size allows it, the three launches of fft2.hip otherwise (N = 64, DPIR_PROX_FUSED=0).  Same bodies, same bits.
-static Status prox_passes(dpir_engine* e, const ProxState& st, ProxFusedArgs a) {
+// The half-spectrum prox passes described by `a` (rows forward -> columns with the solve -> rows inverse) on the layout the spectra were built in:
+// wave-per-transform kernels on the column-major spectrum (fft4.hip, 256 x 256) or the two-pass register kernels (fft2.hip).
+static Status prox_passes(dpir_engine* e, const ProxState& st, const ProxPassArgs& a) {
     hipStream_t s = e->stream;
     const int P = st.B * 3, N = st.W;
-    a.P = P; a.WP = st.WP;
+    const RenoiseArgs ra{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
     if (st.colmajor) {
         DPIR_TRY(launch_rfft4_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, st.WP, a.fu.eps6, a.fu.out_ch, a.slot_col));
-        DPIR_TRY(launch_cfft4_cols(s, a.tw, a.hbuf, a.solve, true, P, st.WP));
-        const RenoiseArgs ra4{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
-        return launch_irfft4_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, st.WP, a.rn.xt ? &ra4 : nullptr, a.col_slot);
-    }
-    if (e->prox_mode == 1 && prox_fused_supported(st.H, st.W, st.sf)) {
-        a.K = prox_fused_round(P);
-        a.nr_max = (P + a.K - 1) / a.K + 12;
-        const size_t words = prox_fused_sync_words(P, a.K);
-        const uint64_t gen = e->ws.generation;
-        DPIR_TRY(e->ws.getT("prox#sync", words, &a.sync));
-        if (e->ws.generation != gen) DPIR_HIP(hipMemsetAsync(a.sync, 0, words * sizeof(unsigned), s));      // fresh buffer; afterwards the kernel cleans up
-        a.err = e->prox_err;
-        e->prox_fused_pending = true;
-        return launch_prox_fused(s, a, N, st.sf, e->cus);
+        DPIR_TRY(launch_cfft4_cols(s, a.tw, a.hbuf, a.solve, true, P, st.WP, e->cus));
+        return launch_irfft4_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, st.WP, a.rn.xt ? &ra : nullptr, a.col_slot);
     }
     DPIR_TRY(launch_rfft_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, N, a.fu.eps6, a.fu.out_ch, a.slot_col));
     DPIR_TRY(launch_cfft_cols(s, a.tw, a.hbuf, a.solve, true, P, st.H));
-    const RenoiseArgs ra{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
     return launch_irfft_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, N, a.rn.xt ? &ra : nullptr, a.col_slot);
 }
 
@@ -600,7 +584,7 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
         float2* hbuf = nullptr;
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)st.B * 3 * st.H * st.WP, &hbuf));
         ProfScope ps2(&e->prof, PC_FFT);
-        ProxFusedArgs a{};
+        ProxPassArgs a{};
         a.x = x; a.pa = pa; a.pb = pb; a.pm = alpha; a.sp = sp; a.fu = RowsFuse{nullptr, 0}; a.slot_col = st.slot_col;
         a.solve = SolveArgs{st.FB, st.F2B, st.FBFy, alpha, st.sf, sp, st.invW, st.slot_col};
         a.out = out; a.scale = 1.0f / ((float)st.H * (float)st.W); a.oa = oa; a.ob = ob;
@@ -625,7 +609,7 @@ static Status data_solution_impl(dpir_engine* e, const ProxState& st, const floa
 }
 
 int dpir_set_prox_launch(dpir_engine* e, int mode) {
-    if (!e || mode < 0 || mode > 2) return fail(e, invalid("dpir_set_prox_launch: mode must be 0, 1 or 2"));
+    if (!e || (mode != 0 && mode != 1)) return fail(e, invalid("dpir_set_prox_launch: mode must be 0 or 1"));
     (void)hipSetDevice(e->device);
     if (mode != e->prox_mode) { (void)hipStreamSynchronize(e->stream); e->invalidate_graphs(); }
     e->prox_mode = mode;
@@ -917,7 +901,7 @@ Status loop_step(dpir_engine* e, const dpir_loop_desc& d, const LoopBufs& b, Pro
         float2* hbuf = nullptr;
         DPIR_TRY(e->ws.getT("prox#hbuf", (size_t)prox->B * 3 * prox->H * prox->WP, &hbuf));
         ProfScope ps(&e->prof, PC_FFT);
-        ProxFusedArgs a{};
+        ProxPassArgs a{};
         a.x = b.x; a.pa = 0.5f; a.pb = 0.5f; a.pm = 1.f; a.sp = b.cur; a.fu = RowsFuse{b.out6, e->net.desc.out_channels}; a.slot_col = prox->slot_col;
         a.solve = SolveArgs{prox->FB, prox->F2B, prox->FBFy, 1.f, prox->sf, b.cur, prox->invW, prox->slot_col};
         a.out = b.x0; a.scale = 1.0f / ((float)H * (float)W); a.oa = 2.f; a.ob = -1.f; a.blend_base = nullptr; a.g = 1.f;
@@ -1035,7 +1019,7 @@ static int run_loop_once(dpir_engine* e, const dpir_loop_desc* dd, const dpir_st
     ProxState& prox = e->loop_prox;
     // sf decides the spectrum layout (half-spectrum register FFT vs bit-reversed c2c): a change of sf re-allocates too
     if (need_prox && (prox.B != B || prox.H != H || prox.W != W || prox.sf != d.sf || prox.half != fft2_supported(H, W, d.sf) ||
-                      prox.colmajor != (e->prox_mode == 2 && fft4_supported(H, W, d.sf)) || !prox.FB)) {
+                      prox.colmajor != (e->prox_mode == 1 && fft4_supported(H, W, d.sf)) || !prox.FB)) {
         API_HIP(e, hipStreamSynchronize(e->stream));
         prox_release(&prox);
         e->invalidate_graphs();
@@ -1215,8 +1199,9 @@ int dpir_p_sample(dpir_engine* e, const float* x_dev, int t, const dpir_psample_
         std::vector<int64_t> yv;
         if (y_host) yv.assign(y_host, y_host + B);
         const dpir_psample_coef cc = *c;
-        ++e->fwd_since_sync;
-        e->replay_last = [=]() { return dpir_p_sample(e, x_dev, t, &cc, noise_dev, yv.empty() ? nullptr : yv.data(), xt_out_dev, x0_out_dev, B, H, W); };
+        if (x_dev != xt_out_dev && x_dev != x0_out_dev)
+            e->arm_replay([=]() { return dpir_p_sample(e, x_dev, t, &cc, noise_dev, yv.empty() ? nullptr : yv.data(), xt_out_dev, x0_out_dev, B, H, W); });
+        else { ++e->fwd_since_sync; e->replay_last = nullptr; }
     }
     return DPIR_OK;
 }

@@ -70,7 +70,9 @@ struct Profiler {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
         hipEvent_t e; (void)hipEventCreate(&e); return e;
     }
+    unsigned long long serial = 0;      // every scoped enqueue bumps it, profiling on or off: "has anything been enqueued since X?" (api.hip replay guard)
     int begin(int cls) {
+        ++serial;
         if (!on) return -1;
         Rec r; r.a = get(); r.b = get(); r.cls = cls;
         (void)hipEventRecord(r.a, stream);

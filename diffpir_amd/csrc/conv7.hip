@@ -18,6 +18,7 @@
 // (bench.py, DPIR_CONV7=1/0 interleaved in one call, profiles/r04/bench_ab_conv7_in_one_call.log): 8.37 / 8.32 vs 8.19 / 8.21 images/s (the round-3 kernel on / off).
 // PMC (profiles/r04): matrix pipe busy 78.1 % of the cycles at an effective 1.67 GHz (conv6: 74.8 % at 1.62 GHz).
 #include "common.h"
+#include <atomic>
 #include "elem.h"
 #include "lds_dma.h"
 #include "conv6_params.h"
@@ -559,16 +560,19 @@ static Status launch7(hipStream_t s, const Conv6K& k, int blocks) {
 // bound of two).  The fused hop's waiting set -- the workgroups of one (image, co-block) -- must fit with room to spare
 // (conv7_emit_supported: at most HALF of this), instead of the constants 256 / 512 of an MI355X being assumed.
 int conv7_emit_capacity() {
-    static int cap = -1;
-    if (cap >= 0) return cap;
+    static std::atomic<int> caps[16];      // per device ordinal (0 = not asked yet; stored + 1): engines on different devices share this process
     int dev = 0, cus = 0, occ = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return cap = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 0;
+    std::atomic<int>* slot = (dev >= 0 && dev < 16) ? &caps[dev] : nullptr;
+    if (slot && slot->load() > 0) return slot->load() - 1;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
     using G = Geo7<0>;
     constexpr int PATCH = G::TI * ((1 << G::LTH) + 2) * ((1 << G::LTW) + 2);
     constexpr size_t LDS = (size_t)4 * ((2 * PATCH + 63) / 64) * 1024;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, conv7_mfma_kernel<0, false, false, true>, 256, LDS) != hipSuccess || occ < 1) occ = 1;
     if (occ > 2) occ = 2;
-    return cap = cus * occ;
+    if (slot) slot->store(cus * occ + 1);
+    return cus * occ;
 }
 
 // k as launch_conv6 fills it (geometry from H, W as conv6_geo); blocks = pixel tiles x co-blocks x ksplit

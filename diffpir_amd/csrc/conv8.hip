@@ -89,11 +89,11 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_fused_kernel(Conv8K p) {
     const float* ximg = p.x + (size_t)n * p.C * HW;
 
     // BRANCH-FREE on purpose.  The first version guarded every load and every element's transform with `goff >= 0` / the SiLU flag: the compiler
-    // turned each of the 48 elements per step into its own basic block with an `s_waitcnt lgkmcnt(0)` (the GroupNorm table read) in front
+    // turned each of the elements of a step (48 per thread in that 256-thread version; C8_NIT x 8 = 24 at 512 threads) into its own basic block with an `s_waitcnt lgkmcnt(0)` (the GroupNorm table read) in front
     // of a branch -- 400 us per launch at B = 16 (profiles/r05/conv8_first_version_kernel_trace.txt).  Here every lane loads (out-of-image
     // items read offset 0 of their plane, a valid address) and the padding zero is a select at the end.
     // Buffer loads: ONE descriptor for the image (SGPRs), one byte-offset VGPR per item, the channel term (ks * 32 + j) * HW * 4 in the
-    // scalar offset.  With flat `global_load` every one of the 48 loads of a step kept its own 64-bit address (96 VGPRs): spills at the
+    // scalar offset.  With flat `global_load` every one of the loads of a step (48 per thread at 256 threads) kept its own 64-bit address (96 VGPRs): spills at the
     // 256-VGPR budget of two workgroups per CU.
     float v[C8_NIT][8];
     const __amdgpu_buffer_rsrc_t rx = rsrc_uniform(ximg, (unsigned)((size_t)p.C * HW * 4));
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(C8_THREADS, 2) void conv8_fused_kernel(Conv8K p) {
                 s_hi[sidx[it]] = h8;
                 if (!X1) s_lo[sidx[it]] = l8;
             }
-            // keep the scheduler from hoisting the NEXT items' table reads above this point: all six items' 8 x float4 at once are 192
+            // keep the scheduler from hoisting the NEXT items' table reads above this point: all items' 8 x float4 at once (six items = 192 registers in the 256-thread version, C8_NIT = 3 here) are 192
             // live VGPRs on top of the 48 prefetched values -> spills; one item's 32 cost ~60 cycles of exposed LDS latency per item
             __builtin_amdgcn_sched_barrier(0);
         }

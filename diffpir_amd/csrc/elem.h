@@ -104,27 +104,24 @@ Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, flo
 // fft4.hip: one wave per 256-point transform, column-major half spectrum [plane][slot][row] (NC slots per plane); 256 x 256, sf 1 / 2 / 4
 bool fft4_supported(int H, int W, int sf);
 int fft4_columns(int W, int sf);
+int fft4_row_pos(int u);      // position of row u inside a stored column
 void fft4_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>& col_slot);
 Status launch_rfft4_rows(hipStream_t s, const float2* tw, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
                          const float* eps6, int out_ch, const int* slot_col);
 Status launch_irfft4_rows(hipStream_t s, const float2* tw, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g, int P,
                           int NC, const RenoiseArgs* ra, const int* col_slot);
-Status launch_cfft4_cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC);
+Status launch_cfft4_cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC, int cus);
 Status launch_fold_f2b4(hipStream_t s, const float* F2B, const int* slot_col, int NC, int sf, float* invW, int B);
-// fft3.hip: the three passes as ONE persistent launch (per-plane ticketed jobs, XCD-local L2-resident intermediate); N = 256 / 512.
+// the arguments of the three half-spectrum passes (rows forward -> columns with the solve -> rows inverse), whichever kernels run them
 struct RowsFuse { const float* eps6; int out_ch; };      // eps -> x0 prologue of the row pass (loop only)
 struct RenoiseFuse { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };
-struct ProxFusedArgs {
+struct ProxPassArgs {
     const float* x; float pa, pb, pm; const StepDev* sp; RowsFuse fu; const int* slot_col;                       // rows forward
     SolveArgs solve;                                                                                             // columns
     float* out; float scale, oa, ob; const float* blend_base; float g; RenoiseFuse rn; const int* col_slot;     // rows inverse
-    float2* hbuf; const float2* tw; int P, WP;
-    unsigned* sync; unsigned* err; int K, nr_max;       // scheduling words (prox_fused_sync_words, zero before the first launch), planes per round
+    float2* hbuf; const float2* tw;
 };
-bool prox_fused_supported(int H, int W, int sf);
-int prox_fused_round(int P);
-size_t prox_fused_sync_words(int P, int K);
-Status launch_prox_fused(hipStream_t s, const ProxFusedArgs& a, int N, int sf, int cus);
+
 Status launch_psf_embed_real(hipStream_t s, const float* k, int kh, int kw, float* out, int B, int H, int W);
 
 }  // namespace dpir

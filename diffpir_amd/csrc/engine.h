@@ -134,17 +134,21 @@ struct dpir_engine {
         graphs.clear();
     }
     unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
-    // fft3.hip, the single-launch FFT prox: device error word (a bounded dependency wait gave up), set when a fused launch has been issued
-    // since the last check, CU count of the device, on / off (DPIR_PROX_FUSED=0: the three launches of fft2.hip)
-    // prox_mode (dpir_set_prox_launch): 2 = wave-per-transform kernels on a column-major spectrum (fft4.hip; 256 x 256, the default), 1 = fft2's bodies as
-    // one persistent launch (fft3.hip), 0 = fft2's three launches; sizes a mode does not cover fall back to 0
-    unsigned* prox_err = nullptr; bool prox_fused_pending = false; int cus = 256; int prox_mode = 2;
+    // how the half-spectrum data step is run (dpir_set_prox_launch): 1 = wave-per-transform kernels on a column-major spectrum (fft4.hip; 256 x 256, default),
+    // 0 = the two-pass register kernels (fft2.hip; every other size always).  cus: CU count of the device.
+    int prox_mode = 1; int cus = 256;
     // conv7's fused hop (Conv6Emit) is an inter-workgroup wait; when it times out (the GPU is shared with other engines / processes) the
     // engine does not fail: it switches the hop off for its lifetime and re-runs what the time-out invalidated -- the restoration loop
     // (dpir_run_loop) or the ONE eager forward issued since the last synchronisation (replay_last); see dpir_check_range
     bool fuse_h1_off = false;
     int fwd_since_sync = 0;
     std::function<int()> replay_last;
+    // the replay is valid only while NOTHING has been enqueued behind that forward (later work consumed its invalid output) and none of its buffers
+    // has been freed: the enqueue serial (Profiler::serial + copies) at the moment the forward returned
+    unsigned long long replay_serial = 0;
+    unsigned long long enqueue_serial() const { return prof.serial + copy_serial; }
+    unsigned long long copy_serial = 0;
+    void arm_replay(std::function<int()> fn) { ++fwd_since_sync; replay_last = std::move(fn); replay_serial = enqueue_serial(); }
     void* comm = nullptr; int comm_world = 1, comm_rank = 0;     // RCCL communicator (comm.cpp), or null
 
     dpir::Status fft_plan(int N, dpir::FftPlan* out);

@@ -1,5 +1,5 @@
-// Device bodies of the half-spectrum register-FFT prox (utils/utils_sisr.py:9-19, 65-95), shared by the three-launch path (fft2.hip: one
-// kernel per pass) and the single persistent launch (fft3.hip: the same bodies as ticketed jobs of one kernel).  A body is written for
+// Device bodies of the half-spectrum register-FFT prox (utils/utils_sisr.py:9-19, 65-95), used by fft2.hip (one kernel per pass); written as bodies of a job index so that
+// a persistent single launch can run them as ticketed jobs (tried and measured slower: tools/dead_ends/prox_single_launch).  A body is written for
 // a block of THREADS threads and a job index `bid` (what blockIdx.x is in the three-launch kernels); its arithmetic does not depend on
 // THREADS, so both paths produce the same bits.
 //   PERSIST = false: the body stages the twiddle table itself (requested first, stored once its own loads are in flight);

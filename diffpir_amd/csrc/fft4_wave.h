@@ -22,15 +22,25 @@ namespace dpir {
 
 struct WaveTw { float2 t16[3]; float2 t256[4]; };     // per-lane constants: W16^(g a), a = 1..3;  W256^(c (g + 4 b)), b = 0..3
 
-// tw: table of W_256^m = (cos, -sin)(2 pi m / 256), m < 256 (global or LDS)
+// The seven constants of lane l are the same for every wave: the host lays them out as a [7][64] table BEHIND the 256 entries of the W_256^m table
+// (wave_tw_fill), so a wave reads them as seven fully contiguous 512-byte loads instead of seven 64-address gathers.
+constexpr int WAVE_TW_OFFSET = 256, WAVE_TW_COUNT = 7 * 64;
 __device__ __forceinline__ WaveTw wave_tw_load(const float2* tw, int lane) {
-    const int g = lane >> 4, c = lane & 15;
+    const float2* t = tw + WAVE_TW_OFFSET + lane;
     WaveTw w;
 #pragma unroll
-    for (int a = 1; a < 4; ++a) w.t16[a - 1] = tw[(16 * g * a) & 255];
+    for (int a = 0; a < 3; ++a) w.t16[a] = t[64 * a];
 #pragma unroll
-    for (int b = 0; b < 4; ++b) w.t256[b] = tw[(c * (g + 4 * b)) & 255];
+    for (int b = 0; b < 4; ++b) w.t256[b] = t[64 * (3 + b)];
     return w;
+}
+// host: out[WAVE_TW_COUNT] from the table of W_256^m
+inline void wave_tw_fill(const float2* w256, float2* out) {
+    for (int lane = 0; lane < 64; ++lane) {
+        const int g = lane >> 4, c = lane & 15;
+        for (int a = 1; a < 4; ++a) out[64 * (a - 1) + lane] = w256[(16 * g * a) & 255];
+        for (int b = 0; b < 4; ++b) out[64 * (3 + b) + lane] = w256[(c * (g + 4 * b)) & 255];
+    }
 }
 
 // first.upper half <-> second.lower half (lanes 32..63 / 0..31)

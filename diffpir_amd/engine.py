@@ -165,9 +165,9 @@ class Engine:
     precision = "f32"
 
     def set_prox_launch(self, mode):
-        """'wave' / 2: wave-per-transform kernels on a column-major spectrum (csrc/fft4.hip, 256 x 256; default); 'fused' / 1: fft2's passes as one
-        persistent launch (csrc/fft3.hip); 'launches' / 0: fft2's three launches.  Takes effect at the next pre_calculate / loop call."""
-        m = {"wave": 2, "fused": 1, "launches": 0}.get(mode, mode)
+        """'wave' / 1: wave-per-transform kernels on a column-major spectrum (csrc/fft4.hip, 256 x 256; default); 'launches' / 0: the two-pass register
+        kernels (csrc/fft2.hip).  Takes effect at the next pre_calculate / loop call."""
+        m = {"wave": 1, "launches": 0}.get(mode, mode)
         self._check(self.lib.dpir_set_prox_launch(self.h, int(m)))
 
     def enable_grad(self, on=True):

@@ -163,10 +163,35 @@ def make_operators(config, n, idx0, H, W):
                 _MAT_CACHE["warned"] = True
             kk = synth.bicubic_psf_x4()
         k = np.broadcast_to(kk, (n, 1) + kk.shape).copy()
+    elif config.get("load_mask", False):
+        # main_ddpir.py:103-104: ONE mask image for every test image, `imread_uint(mask_path, n_channels).astype(bool)`
+        mask = load_mask_image(config, H, W)
+        mask = np.broadcast_to(mask, (n,) + mask.shape[1:]).copy()
     else:
         gen = mask_generator(config.mask_type, config.mask_len_range, config.mask_prob_range)
         mask = np.concatenate([gen((1, 3, H, W)) for _ in range(n)], 0)
     return k, mask
+
+
+def load_mask_image(config, H, W):
+    """`load_mask: true` (main_ddpir.py:103-104): util.imread_uint(mask_path, n_channels) -> astype(bool): any non-zero byte keeps the pixel.
+    Returns uint8 {0, 1} [1, 3, H, W].  A relative mask_path is looked up under `cwd` like the reference's other inputs; a mask whose size differs
+    from the images is an error (the reference would fail at `img_H * mask`)."""
+    path = config.get("mask_path", "")
+    if not path:
+        raise ValueError("load_mask: true needs mask_path (main_ddpir.py:104)")
+    if not os.path.isabs(path) and not os.path.exists(path):
+        path = os.path.join(config.get("cwd", ""), path)
+    if path.endswith(".npy"):
+        m = np.load(path)
+    else:
+        from PIL import Image
+        m = np.asarray(Image.open(path).convert("RGB"), np.uint8)          # imread_uint(n_channels=3): grey images are replicated (utils_image.py:190-199)
+    if m.ndim == 2:
+        m = np.repeat(m[:, :, None], 3, axis=2)
+    if m.shape[:2] != (H, W) or m.shape[2] != 3:
+        raise ValueError(f"mask {path}: shape {m.shape}, the test images are {H} x {W} x 3 (main_ddpir.py:109 multiplies them elementwise)")
+    return np.ascontiguousarray((m != 0).astype(np.uint8).transpose(2, 0, 1)[None])
 
 
 def main(argv=None):

@@ -60,10 +60,11 @@ void dpir_destroy(dpir_engine* e);
 const char* dpir_last_error(const dpir_engine* e);   /* never NULL */
 /* hipStreamSynchronize on the engine stream, then the f16 operand range guard (DPIR_ERR_RANGE, above).  Also the point where a time-out of
  * conv7's fused GroupNorm hop (an inter-workgroup wait; only seen when 3+ engines / processes share the GPU) is handled: the engine switches
- * the hop off for its lifetime, re-issues the ONE eager forward (dpir_unet_forward / dpir_model_fn_xstart / dpir_p_sample) outstanding since
- * the last synchronisation on the unfused path and returns DPIR_OK with correct results; a burst of several un-synchronised eager forwards
- * cannot be re-issued from here and returns DPIR_ERR_HIP ONCE (not sticky: repeat the calls).  dpir_d2h does the same before it copies;
- * dpir_run_loop re-runs itself. */
+ * the hop off for its lifetime and, when the ONE eager forward (dpir_unet_forward / dpir_model_fn_xstart / dpir_p_sample) outstanding since the
+ * last synchronisation is still the LAST work on the stream, its outputs do not alias its inputs and no dpir_free happened since, re-issues it on the
+ * unfused path and returns DPIR_OK with correct results.  Anything else -- several un-synchronised forwards, or other calls (a prox step, dpir_finalize,
+ * a copy) already queued behind the forward, which have consumed its invalid output -- cannot be repaired from here and returns DPIR_ERR_HIP ONCE
+ * (not sticky: repeat the calls).  dpir_d2h does the same before it copies; dpir_run_loop re-runs itself. */
 int dpir_sync(dpir_engine* e);
 /* the engine's hipStream_t, for callers that enqueue their own work (e.g. RCCL) behind it */
 void* dpir_stream(dpir_engine* e);
@@ -151,13 +152,11 @@ int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0_dev, float
  * (use_graph 0) or ONE captured graph of the n applies (use_graph 1: how dpir_run_loop replays the step; no host launch cost, no event record between
  * applies) -> device microseconds per apply, launch boundaries included.  x0 is overwritten n + 1 (+ n) times. */
 int dpir_prox_fft_apply_timed(dpir_engine* e, const dpir_prox* p, float* x0_dev, float tau, float guidance, int n, int use_graph, float* us_per_apply);
-/* How the half-spectrum data_solution (utils/utils_sisr.py:65-75; 256^2 / 512^2, sf 1 / 2 / 4) is launched.  mode 1 (default; env DPIR_PROX_FUSED=0
- * selects 0 at dpir_create): ONE persistent launch -- per-plane ticketed row / column / inverse-row jobs, each plane's half-spectrum intermediate kept in
- * the L2 of the XCD that claimed the plane (csrc/fft3.hip).  mode 0: three dependent launches (csrc/fft2.hip).  Both run the same device bodies and
- * return the same bits; other sizes always use the launches.  A bounded dependency wait that gives up in mode 1 (cannot happen by construction)
- * is reported as DPIR_ERR_HIP by the next dpir_sync / dpir_d2h and switches the engine to mode 0.  Drops the captured step graphs.
- * mode 2 (256 x 256): one wave per 256-point transform on a column-major half spectrum (csrc/fft4.hip).  A dpir_prox keeps the layout of the mode it
- * was created in. */
+/* Which kernels run the half-spectrum data_solution (utils/utils_sisr.py:65-75).  mode 1 (default; env DPIR_PROX_MODE=0 selects 0 at dpir_create), 256 x 256
+ * only: one wave per 256-point transform (64 lanes x 4 points, permlane-swap 4 x 4 transposes, a wave-private LDS tile, no workgroup barrier inside a
+ * transform) on a COLUMN-major half spectrum, csrc/fft4.hip.  mode 0, and every other size: the two-pass register kernels of csrc/fft2.hip (a thread holds
+ * 16 points) on the row-major padded spectrum.  Same mathematics, results within a few 1e-6 of each other.  A dpir_prox keeps the layout of the mode it
+ * was created in (dpir_prox_read returns natural order either way).  Drops the captured step graphs. */
 int dpir_set_prox_launch(dpir_engine* e, int mode);
 /* Replaces main_ddpir.py:392-394: x0_p = (m*(2y-1)+tau*x0)/(m+tau); x0 += g*(x0_p-x0).  mask u8 [B,3,H,W]. */
 int dpir_prox_mask(dpir_engine* e, float* x0_dev, const float* y_dev, const uint8_t* mask_dev,

@@ -74,6 +74,49 @@ def test_data_solution_full_size_vs_oracle_and_roundtrip(engine, H, W, sf):
     assert np.abs(out - z).max() < 1e-3
 
 
+@pytest.mark.parametrize("B,sf", [(5, 1), (3, 4), (3, 2), (16, 1)])
+def test_prox_wave_kernels_match_two_pass_kernels_and_oracle(B, sf):
+    """The two kernel families behind data_solution at 256 x 256 -- one wave per 256-point transform on a column-major spectrum (csrc/fft4.hip, the
+    default) and the two-pass register kernels (csrc/fft2.hip) -- on the same inputs: spectra read back in natural order, dpir_data_solution against the
+    oracle (utils_sisr.py:65-75) in both, dpir_prox_fft_apply with and without the guidance blend against each other, repeated (a racy kernel would differ
+    run to run), and the timed-apply entry."""
+    import diffpir_amd
+    H = 256
+    rng = np.random.default_rng(100 * B + sf)
+    k = rng.random((B, 1, 25, 25)).astype(np.float32); k /= k.sum(axis=(2, 3), keepdims=True)
+    y = rng.random((B, 3, H // sf, H // sf)).astype(np.float32)
+    z = rng.random((B, 3, H, H)).astype(np.float32)
+    opre = do.pre_calculate(torch.from_numpy(y), torch.from_numpy(k), sf)
+    ref = do.data_solution(torch.from_numpy(z), *opre, torch.tensor(0.01).float().repeat(1, 1, 1, 1), sf).numpy()
+    e = diffpir_amd.Engine(0)
+    try:
+        got = {}
+        for mode in ("launches", "wave"):
+            e.set_prox_launch(mode)
+            pre = sr.pre_calculate(e.to_device(y), e.to_device(k), sf)
+            spec = [pre[i].numpy() for i in (0, 2, 3)]
+            out = sr.data_solution(e.to_device(z), *pre, 0.01, sf).numpy()
+            assert np.abs(out - ref).max() < 2e-4 * max(1.0, np.abs(ref).max()), mode
+            applies = []
+            for rep in range(6):
+                d = e.to_device((z * 2 - 1).astype(np.float32))
+                e._check(e.lib.dpir_prox_fft_apply(e.h, pre[0].spectra.handle, d.ptr, 0.02, 1.0 if rep % 2 else 0.6))
+                applies.append(d.numpy())
+            assert np.array_equal(applies[0], applies[2]) and np.array_equal(applies[0], applies[4]) and np.array_equal(applies[1], applies[3]), mode
+            us = C.c_float()
+            d = e.to_device((z * 2 - 1).astype(np.float32))
+            e._check(e.lib.dpir_prox_fft_apply_timed(e.h, pre[0].spectra.handle, d.ptr, 0.05, 1.0, 5, 1, C.byref(us)))
+            assert 1.0 < us.value < 1e4
+            got[mode] = (spec, out, applies)
+        for a, b in zip(got["launches"][0], got["wave"][0]):
+            assert np.abs(a - b).max() <= 2e-6 * max(1.0, np.abs(a).max())
+        assert np.abs(got["launches"][1] - got["wave"][1]).max() < 2e-5
+        for a, b in zip(got["launches"][2], got["wave"][2]):
+            assert np.abs(a - b).max() < 2e-5
+    finally:
+        e.close()
+
+
 def test_prox_fft_apply_matches_loop_expression(engine, golden):
     g = golden("operators")
     y, k = engine.to_device(g["deblur_y"]), engine.to_device(g["deblur_k"])

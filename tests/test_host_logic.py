@@ -331,3 +331,27 @@ def test_yaml_driver_reads_the_reference_kernel_files(tmp_path):
     assert k.shape == (3, 1, 19, 19) and np.array_equal(k[2, 0], g["c2lev_k"][0, 0])
     with pytest.raises(FileNotFoundError):
         drv.make_operators(drv.Config(dict(cwd=str(tmp_path / "nowhere"), task="deblur", use_DIY_kernel=False)), 1, 0, 256, 256)
+
+
+def test_yaml_driver_honours_load_mask(tmp_path):
+    """`load_mask: true` + `mask_path` (main_ddpir.py:103-104): util.imread_uint(mask_path, n_channels=3).astype(bool), the SAME mask for every image.
+    PNG (grey and RGB) through PIL, non-zero bytes keep the pixel; relative paths resolve under cwd; a size mismatch is an error."""
+    from diffpir_amd import main_ddpir as drv
+    from PIL import Image
+    rng = np.random.default_rng(3)
+    m = (rng.random((64, 64)) > 0.4).astype(np.uint8) * 255
+    m[0, 0] = 1                                                # any non-zero byte is True after astype(bool)
+    Image.fromarray(m).save(str(tmp_path / "grey.png"))
+    rgb = np.stack([m, m, np.zeros_like(m)], axis=2)
+    Image.fromarray(rgb).save(str(tmp_path / "rgb.png"))
+    cfg = drv.Config(dict(cwd=str(tmp_path), task="inpaint", load_mask=True, mask_path="grey.png"))
+    _, mask = drv.make_operators(cfg, 3, 0, 64, 64)
+    assert mask.dtype == np.uint8 and mask.shape == (3, 3, 64, 64)
+    assert np.array_equal(mask[2, 1], (m != 0).astype(np.uint8)) and np.array_equal(mask[0], mask[2])
+    cfg = drv.Config(dict(cwd=str(tmp_path), task="inpaint", load_mask=True, mask_path=str(tmp_path / "rgb.png")))
+    _, mask = drv.make_operators(cfg, 1, 0, 64, 64)
+    assert np.array_equal(mask[0, 0], (m != 0).astype(np.uint8)) and not mask[0, 2].any()
+    with pytest.raises(ValueError):
+        drv.make_operators(cfg, 1, 0, 128, 128)
+    with pytest.raises(ValueError):
+        drv.make_operators(drv.Config(dict(cwd=str(tmp_path), task="inpaint", load_mask=True)), 1, 0, 64, 64)

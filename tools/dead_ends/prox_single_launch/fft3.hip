@@ -19,60 +19,15 @@
 //   * self-cleaning state.  The last workgroup to leave zeroes the scheduling words, so a (graph-replayed) launch needs no memset node
 //     in front of it; the words are zeroed once when the buffer is allocated.  Every spin is bounded; a time-out raises `err`.
 #include "fft2_body.h"
+#include "prox_sched.h"
 #include <algorithm>
 
 namespace dpir {
 
-// scheduling words (unsigned): [0] next unclaimed plane, [2] workgroups that left, [16 + 16 x] ticket counter of XCD x,
-// [256 + x * nr_max + r] base plane + 1 of round r of XCD x, then rowdone[P], coldone[P]
-constexpr int PF_TICKET0 = 16, PF_ROUND0 = 256;
 size_t prox_fused_sync_words(int P, int K) { const int nr = (P + K - 1) / K + 12; return (size_t)PF_ROUND0 + 8 * (size_t)nr + 2 * (size_t)P; }
 
 namespace {
 
-#ifndef DPIR_PROX_ACQ
-#define DPIR_PROX_ACQ 0      // 1: the waiting workgroup drops its CU's L1 (agent-scope acquire) after the poll
-#endif
-#ifndef DPIR_PROX_REL
-#define DPIR_PROX_REL 0      // 1: the producing workgroup writes the XCD's L2 back (agent-scope release) before it signals
-#endif
-
-__device__ __forceinline__ unsigned ld_relaxed(const unsigned* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ unsigned add_relaxed(unsigned* p, unsigned v) { return __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-
-constexpr unsigned PF_SPIN_LIMIT = 4u << 20;        // x >= 0.3 us per poll: seconds, never a hang
-// all threads call; thread 0 polls `ctr` until it reaches `target`
-struct DepWait {
-    const unsigned* ctr; unsigned target; unsigned* err;
-    __device__ __forceinline__ void operator()() const {
-        if (threadIdx.x == 0) {
-            unsigned spins = 0;
-            while (ld_relaxed(ctr) < target) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++spins > PF_SPIN_LIMIT) { atomicOr(err, 1u); break; }
-            }
-#if DPIR_PROX_ACQ
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#endif
-        }
-        __syncthreads();
-    }
-};
-// all threads call after the job's last store
-__device__ __forceinline__ void job_done(unsigned* ctr) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // every wave: its stores have reached the L2
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#if DPIR_PROX_REL
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-        add_relaxed(ctr, 1u);
-    }
-}
-
-// waves per SIMD the register allocator must leave room for (= resident 256-thread workgroups per CU): the column job holds 2 RJ values,
-// RJ prefetched FBFy values and the transform's temporaries per thread
 template <int R, int RJ, int SF, bool PF, int OCC>
 __global__ __launch_bounds__(256, OCC) void prox_fused_kernel(const ProxFusedArgs a) {
     constexpr int N = R * RJ, THREADS = 256, SLOTS = THREADS / R, CS = THREADS / R;

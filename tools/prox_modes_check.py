@@ -1,6 +1,6 @@
-"""The single-launch FFT prox (csrc/fft3.hip) against the three launches (csrc/fft2.hip): bitwise equality of dpir_prox_fft_apply /
-dpir_data_solution results over repeated calls (a stale hand-off shows as a mismatch), and us per apply of both.  GPU box only.
-usage: python tools/prox_fused_check.py [reps]"""
+"""The wave-per-transform prox kernels (csrc/fft4.hip, mode 'wave') against the two-pass kernels (csrc/fft2.hip, mode 'launches'): spectra and
+dpir_prox_fft_apply results over repeated calls (run-to-run mismatches counted), and us per apply of both (per-apply events, graph, eager).  GPU box only.
+usage: python tools/prox_modes_check.py [reps]"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -17,7 +17,7 @@ for (B, H, sf) in ((16, 256, 1), (64, 256, 1), (1, 256, 1), (5, 256, 1), (16, 25
     kd = eng.to_device(kk)
     x0h = (rng.random((B, 3, H, H)).astype(np.float32) * 2 - 1)
     res = {}
-    modes = [m for m in os.environ.get("PROX_MODES", "launches,wave").split(",") if not (m == "wave" and H != 256)]
+    modes = [m for m in os.environ.get("PROX_MODES", "launches,wave").split(",") if not (m.startswith("wave") and H != 256)]
     for mode in modes:
         eng.set_prox_launch(mode)
         pre = sr.pre_calculate(y, kd, sf)
