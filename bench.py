@@ -143,7 +143,12 @@ def conv_roofline(eng, B, H, precision, model_name):
 
 
 def prox_roofline(eng, case, B, H, sf):
-    """dpir_prox_fft_apply (x0 -> data-fidelity step -> x0) timed with HIP events on the engine stream."""
+    """dpir_prox_fft_apply (x0 -> data-fidelity step -> x0) timed with HIP events on the engine stream.  `us_per_apply` (what `achieved` uses) is
+    dpir_prox_fft_apply_timed's graph mode: 60 applies captured as ONE hipGraph, one event before and one after its replay -- device time per apply with
+    the launch boundaries between its kernels, which is how dpir_run_loop runs the step (the kernel durations of the rocprofv3 trace under profiles/ add
+    up to the same figure).  `us_per_apply_event_pairs` is the round 1-5 method (an event pair around EVERY eager apply: +2.5 us of record overhead per
+    apply), kept so that the series stays comparable."""
+    import ctypes as C
     from diffpir_amd import utils_sisr as sr
     y, k = eng.to_device(case["y"]), eng.to_device(case["k"])
     pre = sr.pre_calculate(y, k, sf)
@@ -152,6 +157,11 @@ def prox_roofline(eng, case, B, H, sf):
     for _ in range(5):
         eng._check(eng.lib.dpir_prox_fft_apply(eng.h, h, x0.ptr, 0.05, 1.0))
     eng.sync()
+    usg = C.c_float()
+    best = 1e30
+    for _ in range(3):
+        eng._check(eng.lib.dpir_prox_fft_apply_timed(eng.h, h, x0.ptr, 0.05, 1.0, 60, 1, C.byref(usg)))
+        best = min(best, usg.value)
     n = 100
     eng.prof_enable(True)
     eng.prof_reset()
@@ -160,15 +170,20 @@ def prox_roofline(eng, case, B, H, sf):
     eng.sync()
     ms, cnt = eng.prof_read()["fft_prox"]
     eng.prof_enable(False)
-    us = ms / n * 1e3
+    us_ev = ms / n * 1e3
+    us = best
     byts = PROX_BYTES_PER_IMAGE[sf] * B * (H * H) / 65536
     ach = byts / (us * 1e-6) / 1e12
     tr = PMC_TRAFFIC.get(f"fftprox_sf{sf}_B{B}_{H}")        # committed PMC passes: sum of the apply kernels' fabric-side bytes per launch
     traffic = None if tr is None else int(sum(v["bytes_per_launch"] for v in tr["kernels"].values()))
-    return {"bound": "hbm", "kernel": ("rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip half-spectrum path" + ("" if sf == 1 else f", alias-grouped columns, sf = {sf}") + ")")
-            if H in (64, 256) and sf in (1, 2, 4) else "fft.hip c2c path",
+    wave = H == 256 and sf in (1, 2, 4)
+    kern = ("rfft4_rows + cfft4_cols(solve) + irfft4_rows (fft4.hip: one wave per 256-point transform, column-major half spectrum" if wave else
+            "rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip two-pass register kernels, row-major half spectrum" if H in (64, 512) and sf in (1, 2, 4) else "fft.hip c2c path (")
+    return {"bound": "hbm", "kernel": kern + ("" if sf == 1 else f", alias-grouped slots, sf = {sf}") + ")",
             "achieved": round(ach, 4), "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(ach / PEAK_HBM_TBS, 4),
-            "us_per_apply": round(us, 2), "algorithmic_bytes": int(byts), "batch": B, "sf": sf, "launches_per_apply": 3,
+            "us_per_apply": round(us, 2), "us_per_apply_event_pairs": round(us_ev, 2), "frac_event_pairs": round(byts / (us_ev * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
+            "timing": "60 applies as one captured hipGraph between two events (best of 3 replays)",
+            "algorithmic_bytes": int(byts), "batch": B, "sf": sf, "launches_per_apply": 3,
             "traffic": traffic, "traffic_source": None if tr is None else tr["source"]}
 
 
@@ -288,7 +303,7 @@ def main():
             rng = np.random.default_rng(7)          # timing only: any y / PSF of the right shapes
             c64 = {"y": rng.random((64, 3, H, H), dtype=np.float32), "gt": rng.random((64, 3, H, H), dtype=np.float32),
                    "k": np.repeat(synth.gaussian_psf(61, 3.0)[None, None], 64, 0)}
-            prox["at_batch_64"] = {kk: v for kk, v in prox_roofline(eng, c64, 64, H, 1).items() if kk in ("achieved", "frac", "us_per_apply")}
+            prox["at_batch_64"] = {kk: v for kk, v in prox_roofline(eng, c64, 64, H, 1).items() if kk in ("achieved", "frac", "us_per_apply", "us_per_apply_event_pairs", "frac_event_pairs")}
 
     # ---- the fused data step of the loop (eps -> x0 prologue + FFT prox + re-noise/Philox epilogue: 3 launches per step)
     if extras and prox is not None and args.task == "deblur":

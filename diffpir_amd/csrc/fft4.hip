@@ -15,36 +15,24 @@
 #include <vector>
 #include <algorithm>
 #include <stdlib.h>
-#include <stdio.h>
 
 namespace dpir {
-namespace {
 
-// Every wave of a batch-16 launch is resident at once and in the same phase: all request, all transform, all store -- the read time and the write
-// time of the pass ADD.  `stagger` > 0 delays the odd workgroups by that many 64-cycle units before their first request, so that their reads overlap
-// the even ones' transforms and stores (the argument of s_sleep is an immediate: a few fixed steps).
-__device__ __forceinline__ void stagger_odd(int stagger) {
-    if (!(blockIdx.x & 1) || stagger <= 0) return;
-    for (int i = 0; i < stagger; i += 8) __builtin_amdgcn_s_sleep(8);
-}
-// the three passes as one launch each (bodies: fft4_body.h)
+// the three passes as one launch each (named kernels: they are what the rocprofv3 summaries under profiles/ list) (bodies: fft4_body.h)
 __global__ __launch_bounds__(RTHREADS) void rfft4_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int NC,
-                                                             const float2* tw, RowsFuse fu, const int* slot_col, int stagger) {
+                                                             const float2* tw, RowsFuse fu, const int* slot_col) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
-    stagger_odd(stagger);
     rows4_body<false>(sm4, blockIdx.x, x, pa, pb, pm, sp, out, NC, tw, WaveTw{}, fu, slot_col);
 }
 __global__ __launch_bounds__(RTHREADS) void irfft4_rows_kernel(const float2* in, float* out, float scale, float oa, float ob, const float* blend_base, float g,
-                                                              int NC, const float2* tw, RenoiseFuse rn, const int* col_slot, int stagger) {
+                                                              int NC, const float2* tw, RenoiseFuse rn, const int* col_slot) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
-    stagger_odd(stagger);
     irows4_body<false>(sm4, blockIdx.x, in, out, scale, oa, ob, blend_base, g, NC, tw, WaveTw{}, rn, col_slot, NoWait4{});
 }
 // grid: P * ceil(NC / 4) workgroups of four waves: one item each
 template <int MODE, int SF>
-__global__ __launch_bounds__(THREADS4) void cfft4_cols_kernel(float2* buf, SolveArgs a, int NC, const float2* tw, int stagger) {
+__global__ __launch_bounds__(THREADS4) void cfft4_cols_kernel(float2* buf, SolveArgs a, int NC, const float2* tw) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
-    stagger_odd(stagger);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (NC + WAVES - 1) / WAVES;
     const int plane = blockIdx.x / groups;
@@ -72,8 +60,6 @@ __global__ void fold_f2b4_kernel(const float* F2B, const int* slot_col, int NC, 
     }
 }
 
-}  // namespace
-
 int fft4_row_pos(int u) { return pos4(u); }
 bool fft4_supported(int H, int W, int sf) { return H == 256 && W == 256 && (sf == 1 || sf == 2 || sf == 4); }
 // stored columns (slots) per plane: W/2 + 1 for sf = 1, sf * (W/sf/2 + 1) alias-grouped slots otherwise
@@ -93,12 +79,6 @@ void fft4_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>&
         }
 }
 
-// development switch DPIR_FFT4_STAGGER="rows,cols,irows" (64-cycle units)
-static int stagger_of(int which) {
-    static int v[3] = {-1, 0, 0};
-    if (v[0] < 0) { v[0] = 0; if (const char* e = getenv("DPIR_FFT4_STAGGER")) sscanf(e, "%d,%d,%d", &v[0], &v[1], &v[2]); }
-    return v[which];
-}
 static size_t lds4(bool fold, int sf) { return ((size_t)WAVES * WLDS + (fold ? (size_t)WAVES * (N4 / sf) : 0)) * sizeof(float2); }
 static size_t lds4_rows(int NC) { return (size_t)RW * WLDS * sizeof(float2) + (size_t)NC * TST * sizeof(float4); }
 
@@ -107,7 +87,7 @@ Status launch_rfft4_rows(hipStream_t s, const float2* tw, const float* x, float 
     if (eps6 && !sp) return invalid("rfft4_rows: the fused x0 prologue reads its coefficients from the device step block");
     const size_t pairs = (size_t)P * N4 / 2;            // a multiple of RW: no partial workgroup
     hipLaunchKernelGGL(rfft4_rows_kernel, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(NC), s, x, pa, pb, pm, sp, out, NC, tw,
-                       RowsFuse{eps6, out_ch}, slot_col, stagger_of(0));
+                       RowsFuse{eps6, out_ch}, slot_col);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -117,19 +97,19 @@ Status launch_irfft4_rows(hipStream_t s, const float2* tw, const float2* in, flo
     if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
     const size_t pairs = (size_t)P * N4 / 2;
     hipLaunchKernelGGL(irfft4_rows_kernel, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(N4 / 2 + 1), s, in, out, scale, oa, ob, blend, g, NC,
-                       tw, rn, col_slot, stagger_of(2));
+                       tw, rn, col_slot);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
 Status launch_cfft4_cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC, int cus) {
     (void)cus;
     const unsigned grid = (unsigned)(P * ((NC + WAVES - 1) / WAVES));
-    if (!solve) hipLaunchKernelGGL((cfft4_cols_kernel<0, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw, stagger_of(1));
-    else if (a.sf == 1) hipLaunchKernelGGL((cfft4_cols_kernel<2, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw, stagger_of(1));
+    if (!solve) hipLaunchKernelGGL((cfft4_cols_kernel<0, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw);
+    else if (a.sf == 1) hipLaunchKernelGGL((cfft4_cols_kernel<2, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw);
     else {
         if ((a.sf != 2 && a.sf != 4) || !a.invW || !a.slot_col || NC % a.sf) return invalid("cfft4_cols: bad sf > 1 arguments");
-        if (a.sf == 2) hipLaunchKernelGGL((cfft4_cols_kernel<3, 2>), dim3(grid), dim3(THREADS4), lds4(true, 2), s, buf, a, NC, tw, stagger_of(1));
-        else hipLaunchKernelGGL((cfft4_cols_kernel<3, 4>), dim3(grid), dim3(THREADS4), lds4(true, 4), s, buf, a, NC, tw, stagger_of(1));
+        if (a.sf == 2) hipLaunchKernelGGL((cfft4_cols_kernel<3, 2>), dim3(grid), dim3(THREADS4), lds4(true, 2), s, buf, a, NC, tw);
+        else hipLaunchKernelGGL((cfft4_cols_kernel<3, 4>), dim3(grid), dim3(THREADS4), lds4(true, 4), s, buf, a, NC, tw);
     }
     DPIR_HIP(hipGetLastError());
     return Status{};

@@ -267,7 +267,7 @@ def reference_config(ydict, cwd):
         sys.argv = argv
 
 
-def run_test_rho(ydict, batches, model, diffusion, noise_fn=None, sweep=False, trace=None, direct=None):
+def run_test_rho(ydict, batches, model, diffusion, noise_fn=None, sweep=False, trace=None, direct=None, ns_over=None):
     """Execute the reference's test_rho on `batches`.
 
     ydict   : YAML dict (yaml_for(...)); `direct` = {attr: value} set on config AFTER parse_args_and_config -- the values the sweep
@@ -275,6 +275,8 @@ def run_test_rho(ydict, batches, model, diffusion, noise_fn=None, sweep=False, t
     batches : list of (img_H u8 [B,H,W,C], img_L float [B,h,w,C] in [0,1], names, k [B,kh,kw], mask [B,H,W,C]) torch tensors,
               what DataLoader(CustomDataset) yields (main_ddpir.py:117, 262-267).
     sweep   : run the reference's own lambda/zeta sweep statements (main_ddpir.py:549-581) instead of one direct call.
+    ns_over : {name: object} bound in test_rho's globals INSTEAD of the reference's own (`utils_model`, `sr`, `Resizer` ...): recording wrappers
+              around the real plugs (oracle/gen_golden_shim_trace.py)
     returns : (list of x_0 tensors in the order test_rho produced them, config, test_results_ave)
     """
     md = main_module()
@@ -313,6 +315,7 @@ def run_test_rho(ydict, batches, model, diffusion, noise_fn=None, sweep=False, t
         ns.update(config=config, device=device, logger=logger, dataloader=batches, model=model, diffusion=diffusion,
                   util=util, utils_model=um,
                   test_results_ave=OrderedDict(psnr_sf=[], psnr_y_sf=[]))
+        ns.update(ns_over or {})
         _exec(pieces["schedule"], ns)           # betas ... reduced_alpha_cumprod, config.noise_model_t, config.t_start
         _exec(pieces["freeze"], ns)             # requires_grad = False unless DPS_y0
         _exec(pieces["test_rho_deblur" if config.task == "deblur" else "test_rho"], ns)           # def test_rho(config)
@@ -328,7 +331,7 @@ def _nhwc(t):
     return t.permute(0, 2, 3, 1).contiguous()
 
 
-def restore_ref(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_label=None, trace=None, gt_u8=None):
+def restore_ref(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_label=None, trace=None, gt_u8=None, ns_over=None):
     """One batch through the reference's test_rho; `cfg` is an oracle.diffpir_oracle.LoopConfig (the YAML keys that reach the loop,
     already in test_rho's units: lambda_/zeta are the values AFTER the sweep's multipliers, noise_level_img is /255).
     y: [B,3,h,w] in [0,1]; k: [B,1,kh,kw]; mask: [B,3,H,W].  Returns x_0 [B,3,H,W] in [0,1] (main_ddpir.py:470)."""
@@ -352,7 +355,7 @@ def restore_ref(model, diffusion, cfg, y, k=None, mask=None, noise_fn=None, y_la
     # parse_args_and_config re-derives sigma = max(0.001, noise_level_img/255) from the YAML; x255 then /255 may move the last bit of
     # noise_level_img, so the exact value of the case is put back (it is what the fixtures of rounds 1-4 were generated with)
     direct = dict(noise_level_img=float(cfg.noise_level_img), noise_level_model=float(cfg.noise_level_img), sigma=max(0.001, float(cfg.noise_level_img)))
-    outs, config, _ = run_test_rho(yd, [(img_H, img_L, names, kk, mm)], net, diffusion, noise_fn=noise_fn, trace=trace, direct=direct)
+    outs, config, _ = run_test_rho(yd, [(img_H, img_L, names, kk, mm)], net, diffusion, noise_fn=noise_fn, trace=trace, direct=direct, ns_over=ns_over)
     assert len(outs) == 1
     return outs[0]
 

@@ -55,8 +55,8 @@ out = {
     "ffhq_B16_256_f16x3": klass(d, "ffhq_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel|conv8_fused_kernel", src),
     "ffhq_B16_256_f32": klass(d, "ffhq_f32", r"conv2_mfma_kernel<3|conv2_mfma_kernel<1, 8|conv_mfma_kernel<3", src),
     "imagenet256_B32_256_f16x3": klass(d, "in256_f16x3", r"conv7_mfma_kernel|conv6_mfma_kernel|conv8_fused_kernel", src),
-    "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
-    "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
+    "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft4_rows_kernel|cfft4_cols_kernel<2|irfft4_rows_kernel|rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
+    "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft4_rows_kernel|cfft4_cols_kernel<3|irfft4_rows_kernel|rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
 }
 out["ffhq_B16_256_f16x3"]["whole_forward"] = whole_forward(d, "ffhq_f16x3")
 out["imagenet256_B32_256_f16x3"]["whole_forward"] = whole_forward(d, "in256_f16x3")
