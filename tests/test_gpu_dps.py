@@ -163,6 +163,41 @@ def test_dps_y0_loop_full_size_ffhq_vs_oracle():
         e.close()
 
 
+def test_dps_y0_full_size_engine_side_is_bitwise_repeatable():
+    """Round-5 review item 2: ONE full-suite run recorded 8.9e-4 on test_dps_y0_loop_full_size_ffhq_vs_oracle where every other run shows 1.6e-6.  The engine
+    side of that test repeated in one process -- the loop eight times, two back-to-back VJPs per repetition, a second engine created / destroyed and a plain
+    loop on the same engine in between (what the suite does around it) -- must be BITWISE identical every time: the gradient path has no atomics and no
+    run-dependent reduction order.  (tools/dps_repeat.py is the long form: 100 repetitions with churn and with recycled, pattern-filled device memory were
+    bit-identical on two boxes, profiles/r06/README.md.)"""
+    from diffpir_amd import synth
+    hp = uo.ffhq_hp()
+    e, _ = _engine(hp, "f16x3")
+    try:
+        case = synth.make_case("sr", 2, 256, 256, seed=31, sf=4)
+        cfg = restore.LoopConfig(task="sr", iter_num=5, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic", generate_mode="DPS_y0")
+        plain = restore.LoopConfig(task="sr", iter_num=3, lambda_=6.0, zeta=0.25, sf=4, sr_mode="cubic")
+        rng = np.random.default_rng(5)
+        xv, gv = rng.standard_normal((2, 3, 256, 256)).astype(np.float32), rng.standard_normal((2, 6, 256, 256)).astype(np.float32)
+        tv = np.array([400, 400], dtype=np.int64)
+        first = first_dx = None
+        for rep in range(8):
+            out = restore.restore_batch(e, cfg, case["y"], noise_source="host", noise_fn=seeded_noise_fn_np(81)).numpy()
+            _, dx1 = e.unet_vjp(e.to_device(xv), tv, e.to_device(gv)); a = dx1.numpy().copy()
+            _, dx2 = e.unet_vjp(e.to_device(xv), tv, e.to_device(gv)); b = dx2.numpy()
+            if first is None:
+                first, first_dx = out.copy(), a.copy()
+            assert np.array_equal(out, first), (rep, float(np.abs(out - first).max()))
+            assert np.array_equal(a, b) and np.array_equal(a, first_dx), rep
+            if rep % 2 == 0:
+                e2, _ = _engine(hp, "f16x3")
+                restore.restore_batch(e2, plain, case["y"], noise_source="device", seed=rep)
+                e2.close()
+            else:
+                restore.restore_batch(e, plain, case["y"], noise_source="device", seed=rep)
+    finally:
+        e.close()
+
+
 def test_dps_yt_and_first_order_loops_match_live_reference_fixture(golden):
     """The two gradient modes that need no network backward: DPS_yt (main_ddpir.py:439-445) and the first-order data step of the
     DiffPIR loop (sub_1_analytic: false, :420-430; replayed step graph), task sr x4, against the reference's own runs."""

@@ -90,3 +90,30 @@ def test_c3_bicubic_psf_sisr_of_a_demo_image_matches_the_reference_sweep(ref, pr
         fft_prox_parity(out, tgt, gt, f"C3 bicubic PSF on 69037.png, {int(ref['c3bic_nfe'])} NFE, sweep pass {ps} (lambda {lambdas[ps]:g}) [{precision}] vs the reference's main()",
                         floor=(float(ref[f"{ftag}_floor_max"]), float(ref[f"{ftag}_floor_rms"])), floor_dpsnr=float(ref[f"{ftag}_floor_dpsnr"]), nfe=int(ref["c3bic_nfe"]))
     e.close()
+
+
+def test_f16x1_reduced_precision_quality_on_the_demo_images(ref):
+    """SURVEY 8f-2, round-5 review item 6: the opt-in reduced-precision mode (f16 operands, ONE MFMA per product -- the reference's own use_fp16 recipe,
+    guided_diffusion/fp16_util.py:15-32, unet.py:618-632) on the inputs the reference ships, not only on a 64^2 synthetic: its |dPSNR| against the
+    reference's fp32 run for C1 (box inpainting, 20 NFE) and C2 (Levin09[0], 20 NFE) on the five demo PNGs.  NOT inside the 1e-3 dB parity contract;
+    the measured change is the mode's quality contract (printed; bounded here at 0.05 dB so that a regression of the mode is caught)."""
+    e = diffpir_amd.Engine(0)
+    e.set_precision("f16x1")
+    make_model(e, uo.ffhq_hp())
+    try:
+        cfg = restore.LoopConfig(task="inpaint", iter_num=int(ref["c1_nfe"]), lambda_=1.0, zeta=1.0, noise_level_img=0.0)
+        out = restore.restore_batch(e, cfg, ref["c1_y"], mask=ref["c1_mask"], noise_source="host", noise_fn=seeded_noise_fn_np(int(ref["c1_seed"])), use_graph=True).numpy()
+        gt = _gt01(ref["c1_gt"])
+        gap1 = abs(restore.psnr_batch(out * 2 - 1, gt * 2 - 1) - restore.psnr_batch(ref["c1_out"] * 2 - 1, gt * 2 - 1))
+        d1 = float(np.abs(out - ref["c1_out"]).max())
+        nfe = int(ref["c2lev20_nfe"])
+        cfg = restore.LoopConfig(task="deblur", iter_num=nfe, lambda_=1 * 7, zeta=0.1 * 3)
+        out = restore.restore_batch(e, cfg, ref["c2lev_y"], k=ref["c2lev_k"], noise_source="host", noise_fn=seeded_noise_fn_np(int(ref["c2lev20_seed"])), use_graph=True).numpy()
+        gt = _gt01(ref["c2lev_gt"])
+        gap2 = abs(restore.psnr_batch(out * 2 - 1, gt * 2 - 1) - restore.psnr_batch(ref["c2lev20_out"] * 2 - 1, gt * 2 - 1))
+        d2 = float(np.abs(out - ref["c2lev20_out"]).max())
+        print(f"f16x1 on the 5 demo images vs the reference's fp32 main(): C1 box inpainting 20 NFE |dPSNR| {gap1:.2e} dB (max pixel diff {d1:.2e}); "
+              f"C2 Levin09[0] {nfe} NFE |dPSNR| {gap2:.2e} dB (max pixel diff {d2:.2e})")
+        assert gap1 < 0.05 and gap2 < 0.05 and np.isfinite(out).all()
+    finally:
+        e.close()
