@@ -76,7 +76,7 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
     const bool use5 = dbg != 0 && ks == 1, use6 = dbg != 0 && ks == 3;
     if (use5) {
         a5.src = CatSrc{x, Cin, nullptr, 0}; a5.prm = a.src.prm; a5.w16 = w16; a5.w16_scale = w16_scale; a5.bias = bias; a5.out = out;
-        a5.B = B; a5.Cout = Cout; a5.H = H; a5.W = W;
+        a5.B = B; a5.Cout = Cout; a5.H = H; a5.W = W; a5.x1 = e->precision == 2;      // f16x1 engine: single-product kernels (hi planes only)
     }
     if (use6) {
         int C8 = 2 * ((Cin + 15) / 16);
@@ -86,6 +86,7 @@ int dpir_debug_conv_bench(dpir_engine* e, int B, int Cin, int Cout, int H, int W
         API_TRY(e, launch_act_split(e->stream, CatSrc{x, Cin, nullptr, 0}, a.src.prm, 0, B, H, W, s16, s16 + plane));
         a6.xhi = s16; a6.xlo = s16 + plane; a6.w16 = w16; a6.w16_scale = w16_scale; a6.bias = bias; a6.out = out;
         a6.B = B; a6.Cin = Cin; a6.Cout = Cout; a6.H = H; a6.W = W; a6.partial = partial; a6.partial_capacity = a.partial_capacity;
+        a6.x1 = e->precision == 2;
     }
     auto run_once = [&]() -> Status {
         if (use5) return launch_conv5(e->stream, a5);

@@ -16,20 +16,21 @@ SHAPES = [(3, 128, 128, 256, 6), (3, 256, 128, 256, 2), (3, 256, 256, 128, 2), (
           (3, 768, 512, 16, 1), (3, 1024, 512, 8, 2), (3, 128, 6, 256, 1), (3, 256, 256, 16, 2), (3, 256, 512, 16, 1),
           (1, 256, 128, 256, 2), (1, 384, 128, 128, 1), (1, 512, 256, 64, 1), (1, 256, 128, 128, 1), (1, 384, 256, 64, 1), (1, 768, 256, 32, 1),
           (1, 128, 256, 64, 1), (1, 1024, 512, 16, 1), (1, 512, 256, 32, 1), (1, 768, 512, 16, 1), (1, 1024, 512, 8, 2), (1, 256, 512, 16, 1)]
-PEAK = 833.3
+PREC = os.environ.get("DIFFPIR_PRECISION", "f16x3")
+PEAK = 2500.0 if PREC == "f16x1" else 833.3      # f16x1: one MFMA per product against the dense f16 peak; f16x3: three per product
 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
     shapes = SHAPES[:int(sys.argv[2])] if len(sys.argv) > 2 else SHAPES
-    e = diffpir_amd.Engine(0); e.set_precision("f16x3")
+    e = diffpir_amd.Engine(0); e.set_precision(PREC)
     dbg = _lib.load_debug()
     ms = C.c_double(0)
     tot = {1: 0.0, 3: 0.0}; fl = {1: 0.0, 3: 0.0}
     # warm-up: the first launches of a process run ~15 % slower (clock ramp; measured: the same shape 411 us first, 347 us ten configs later,
     # profiles/r04/conv7_128_128_same_work_different_image_shapes.log) -- keep the chip busy for ~50 ms before the first figure
     dbg.dpir_debug_conv_bench(e.h, B, 128, 128, 128, 128, 3, 0, 0, 2, 200 if B <= 16 else 80, C.byref(ms))
-    print(f"FFHQ conv shapes at B = {B}, f16x3, back-to-back launches after a warm-up (us per launch, TF/s-eq, fraction of {PEAK})")
+    print(f"FFHQ conv shapes at B = {B}, {PREC}, back-to-back launches after a warm-up (us per launch, TF/s-eq, fraction of {PEAK})")
     for ks, cin, cout, h, cnt in shapes:
         flops = 2.0 * cin * cout * ks * ks * h * h * B
         iters = 5 if flops > 2e11 else 20
