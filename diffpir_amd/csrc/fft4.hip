@@ -1,15 +1,15 @@
 // fft4: the half-spectrum FFT prox at N = 256 (utils/utils_sisr.py:9-19, 65-95; the headline deblurring / SR configurations) with ONE WAVE PER
-// TRANSFORM (fft4_wave.h) and a COLUMN-MAJOR half spectrum.  Same mathematics as fft2.hip (row-pair packing, half spectrum, closed-form solve between
-// the column transforms), different mapping to the machine:
-//   * rows    : a wave takes one pair of real rows: float4 loads, wave-private LDS re-distribution, 256-point FFT in the wave, Hermitian un-packing,
-//               and writes {A[k], B[k]} of its two rows as ONE 16-byte store into the column-major spectrum [plane][slot][row] (rows r, r + 1 adjacent);
-//   * columns : a wave takes one column (2 KB contiguous): forward FFT -> closed-form solve on registers whose operands (FBFy, FB, F2B, stored
-//               column-major too) are 512-byte contiguous wave loads -> inverse FFT -> store.  No workgroup barrier, no strips, no padding columns
-//               (129 stored columns instead of 144);
-//   * rows inv: a wave gathers {A, B}[k] of its row pair (16-byte loads), Hermitian re-packing through the LDS tile, inverse FFT, float4 epilogue
-//               (x*2-1, guidance blend, or the fused re-noise with Philox draws per float4 group exactly as fft2's).
-// A batch-16 apply is 6 waves per SIMD in every pass (fft2: 1.5), each of them ~60 VGPRs.
-// sf > 1 keeps fft2's alias-grouped SLOT order (slot sf q + b = alias b of fold group q): a workgroup's four waves are four consecutive slots, i.e.
+// TRANSFORM (fft4_wave.h) and a COLUMN-MAJOR half spectrum [plane][slot][position].  Same mathematics as fft2.hip (row-pair packing, half spectrum,
+// closed-form solve between the column transforms), different mapping to the machine (bodies: fft4_body.h):
+//   * rows    : a workgroup = 8 waves = 8 pairs of real rows (row r with r + 64): float4 loads, wave-private LDS re-distribution, 256-point FFT in the wave,
+//               Hermitian un-packing into an LDS tile [slot][8 + 1] of 16-byte {A[k], B[k]} entries, then FULL 128-byte lines (16 positions of one slot) to memory;
+//   * columns : a wave takes one column (2 KB contiguous; position order: two 1 KB wave loads): forward FFT -> closed-form solve on registers whose operands
+//               (FBFy, FB, F2B, stored the same way by pre_calculate) are loaded with the column -> inverse FFT -> store.  No workgroup barrier (sf = 1), no strips,
+//               no padding columns (129 stored columns instead of fft2's 144);
+//   * rows inv: the workgroup loads its 16 positions of columns 0..128 as full lines into the tile, each wave re-packs its pair (Hermitian), inverse FFT, float4
+//               epilogue (x*2-1, guidance blend, or the fused re-noise with Philox draws per float4 group exactly as fft2's).
+// A batch-16 apply is 6 waves per SIMD in every pass (fft2: 1.5) at 40-57 VGPRs.  Measured 24.9 us per apply against fft2's 33.0.
+// sf > 1 keeps fft2's alias-grouped SLOT order (slot sf q + b = alias b of fold group q): a workgroup's four column waves are four consecutive slots, i.e.
 // one fold group at sf = 4 and two at sf = 2; the row aliases u + a N/sf of a column live in ONE lane (registers j, since N/sf is a multiple of 64).
 #include "fft4_body.h"
 #include <vector>

@@ -19,8 +19,8 @@ constexpr int WLDS = 320;        // float2 per wave: the 16 x 18 transpose tile;
 constexpr int RW = 8, RTHREADS = 64 * RW, TST = RW + 1;
 
 // Row order INSIDE a stored column: position pos(u) = 2 (u & 63) + ((u >> 6) & 1) + 128 (u >> 7), so that the four rows lane l of a column wave owns
-// (u = l + 64 j) are positions {2l, 2l + 1, 128 + 2l, 129 + 2l}: a complex column is TWO fully contiguous 1 KB wave loads of 16 bytes per lane (8-byte
-// lane loads ran the column pass at 4.4 TB/s against 7.4 for 16-byte ones: profiles/r06).  The row passes pair row r with row r + 64 (any two real rows
+// (u = l + 64 j) are positions {2l, 2l + 1, 128 + 2l, 129 + 2l}: a complex column is TWO fully contiguous 1 KB wave loads of 16 bytes per lane instead of four
+// 512-byte ones (half the requests; measured the same time per apply, profiles/r06 -- the pass is not bound by access width).  The row passes pair row r with row r + 64 (any two real rows
 // can share a complex transform): their {A, B} entries are then adjacent positions, and the eight pairs of a workgroup fill one 128-byte line per slot.
 __host__ __device__ __forceinline__ int pos4(int u) { return 2 * (u & 63) + ((u >> 6) & 1) + 128 * (u >> 7); }
 // pair q (0..127) of a plane: rows rA = (q & 63) + 128 (q >> 6) and rA + 64

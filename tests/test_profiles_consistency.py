@@ -1,5 +1,5 @@
 """The committed evidence is reproducible from the committed raw summaries: profiles/pmc_traffic.json (which bench.py reads for
-`roofline.traffic`) == tools/pmc_traffic.py over profiles/r05/*_pmc_{FETCH,WRITE}_SIZE.txt."""
+`roofline.traffic`) == tools/pmc_traffic.py over profiles/r06/*_pmc_{FETCH,WRITE}_SIZE.txt."""
 import json
 import os
 import shutil
@@ -16,8 +16,8 @@ def _strip(o):
 
 
 def test_pmc_traffic_json_is_what_the_tool_derives_from_the_committed_passes(tmp_path):
-    src = os.path.join(ROOT, "profiles", "r05")
-    dst = tmp_path / "profiles" / "r05"
+    src = os.path.join(ROOT, "profiles", "r06")
+    dst = tmp_path / "profiles" / "r06"
     dst.mkdir(parents=True)
     for f in os.listdir(src):
         if "_pmc_FETCH_SIZE" in f or "_pmc_WRITE_SIZE" in f:
