@@ -971,7 +971,8 @@ static int run_loop_once(dpir_engine* e, const dpir_loop_desc* dd, const dpir_st
 
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* dd, const dpir_step* steps, int n_steps, float* out_f32, uint8_t* out_u8) {
     int rc = run_loop_once(e, dd, steps, n_steps, out_f32, out_u8);
-    if (rc != DPIR_OK || !e->range_ctr || e->precision == 0 || e->fuse_h1_off || e->grad_enabled) return rc;
+    static const bool fuse_env_off = getenv("DPIR_FUSE_H1") && atoi(getenv("DPIR_FUSE_H1")) == 0;       // unet.hip: the hop is not used at all
+    if (rc != DPIR_OK || !e->range_ctr || e->precision == 0 || e->fuse_h1_off || fuse_env_off || e->grad_enabled) return rc;
     // the fused hop may have run: look at the guard word now (the caller synchronises right after the loop anyway) and, on a time-out,
     // run the whole loop again on the unfused path -- same inputs, same noise (device Philox is keyed by seed; host noise buffers are the caller's)
     unsigned long long n = 0;

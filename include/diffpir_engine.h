@@ -246,7 +246,11 @@ typedef struct dpir_loop_desc {
 } dpir_loop_desc;
 
 /* Runs init -> n_steps x ([repaint mix ->] UNet -> [prox ->] re-noise) -> finalize.  Outputs (either may be NULL):
- * out_f32_dev [B,3,H,W] in [0,1] un-clamped (x_0 of main_ddpir.py:470), out_u8_dev [B,H,W,3]. */
+ * out_f32_dev [B,3,H,W] in [0,1] un-clamped (x_0 of main_ddpir.py:470), out_u8_dev [B,H,W,3].
+ * Synchronisation: in the f32 mode, in gradient mode and once the fused hop is off the call returns as soon as the last step is enqueued
+ * (asynchronous on the engine stream).  In the f16 modes with the fused hop on it BLOCKS until the loop has finished: it reads the guard word back
+ * (one 8-byte D2H + hipStreamSynchronize) so that a hop time-out can re-run the whole loop on the unfused path before the caller sees a result --
+ * callers that queue the next batch's uploads behind the loop lose that overlap; DPIR_FUSE_H1=0 trades ~2 % of the step for an asynchronous return. */
 int dpir_run_loop(dpir_engine* e, const dpir_loop_desc* d, const dpir_step* steps_host, int n_steps,
                   float* out_f32_dev, uint8_t* out_u8_dev);
 
