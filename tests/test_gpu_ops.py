@@ -231,3 +231,52 @@ def test_conv7_is_bit_identical_to_conv6(engine):
              (1, 6, 128, 96, 96, -1, 0, 0, 0), (2, 512, 256, 32, 32, 0, 0, 1, 0), (2, 64, 6, 64, 64, -1, 0, 0, 0), (2, 64, 200, 32, 32, 1, 0, 0, 1),
              (2, 64, 3, 64, 64, -1, 0, 0, 1), (3, 48, 24, 40, 72, 0, 1, 0, 0), (2, 512, 32, 32, 32, 1, 0, 1, 0)]
     assert mod.run(iters=1, cases=cases, engine=engine) == 0
+
+
+def test_device_philox_equals_the_independent_numpy_statement(engine):
+    """The perf-mode noise source by construction, not by statistics (round-5 review, weak item 2): dpir_randn against oracle/philox_oracle.py (numpy
+    Philox4x32-10, itself pinned to the Random123 known-answer vectors in the CPU suite) for several (seed, stream, image offset, shape) incl. a
+    per-image size that is not a multiple of 4 and 64-bit seeds / offsets.  Integer stream identical => the normals agree to the float
+    transcendental functions' rounding (device logf / cospif vs float64)."""
+    from oracle import philox_oracle as po
+    for seed, stream, off, B, Cc, H, W in ((1234, 0, 0, 2, 3, 32, 32), (2 ** 40 + 17, 2 + 4 * 7, 5, 3, 3, 16, 24), (99, 1, 2 ** 33 + 1, 1, 1, 7, 9)):
+        out = engine.empty((B, Cc, H, W))
+        engine._check(engine.lib.dpir_randn(engine.h, out.ptr, seed, stream, off, B, Cc, H, W))
+        ref = po.randn(seed, stream, off, B, Cc * H * W).reshape(B, Cc, H, W)
+        np.testing.assert_allclose(out.numpy(), ref, atol=4e-6, rtol=2e-6)
+
+
+@pytest.mark.parametrize("H", [64, 256])
+def test_device_noise_loop_equals_host_noise_loop_fed_with_the_same_philox_draws(H):
+    """dpir_run_loop in the mode the bench times (device Philox noise, drawn inside the fused inverse-row-FFT epilogue at 64^2 / 256^2) against the SAME loop in
+    parity mode fed host tensors that oracle/philox_oracle.py generates with the loop's keying (stream 0 for x_T, 1 + 4 i / 2 + 4 i for step i's eta / zeta
+    draws, global image index = image_offset + n): the perf-mode loop is the parity-mode loop with a different noise SOURCE and nothing else."""
+    import diffpir_amd
+    from diffpir_amd import restore, synth
+    from oracle import philox_oracle as po, unet_oracle as uo
+    from tests.gpu_common import make_model
+    e = diffpir_amd.Engine(0)
+    try:
+        e.set_precision("f16x3")
+        make_model(e, uo.tiny_hp())
+        case = synth.make_case("deblur", 2, H, H, seed=5, ksize=9)
+        cfg = restore.LoopConfig(task="deblur", iter_num=5, lambda_=7.0, zeta=0.3, eta=0.6)
+        seed, off = 4242, 3
+        dev = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="device", seed=seed, image_offset=off, use_graph=True).numpy()
+        state = {"call": 0}
+
+        def noise_fn(shape):            # restore.draw_host_noise's order: x_T, then per step [p_sample (unused), eta, zeta]; the last step only p_sample
+            c = state["call"]; state["call"] += 1
+            if c == 0:
+                stream = 0
+            else:
+                i, kind = divmod(c - 1, 3)
+                stream = {0: 10 ** 6, 1: 1 + 4 * i, 2: 2 + 4 * i}[kind]           # kind 0: p_sample's dead draw -- any numbers
+            B, Cc, hh, ww = shape
+            return po.randn(seed, stream, off, B, Cc * hh * ww).reshape(shape)
+        host = restore.restore_batch(e, cfg, case["y"], k=case["k"], noise_source="host", noise_fn=noise_fn, use_graph=False).numpy()
+        err = float(np.abs(dev - host).max())
+        print(f"device-Philox loop vs host-noise loop fed the numpy Philox draws, {H}^2: max|diff| {err:.3e}")
+        assert err < 1e-4
+    finally:
+        e.close()

@@ -335,3 +335,19 @@ def test_oracle_equals_the_reference_main_run_on_shipped_inputs_bit_for_bit(gold
     with torch.no_grad():
         out = do.restore(sd, hp, cfg, torch.from_numpy(g["c2lev_y"]), k=torch.from_numpy(g["c2lev_k"]), noise_fn=seeded_noise_fn(int(g["c2lev_seed"]))).numpy()
     assert np.array_equal(out, g["c2lev_out"]), float(np.abs(out - g["c2lev_out"]).max())
+
+
+def test_numpy_philox_matches_the_random123_known_answers():
+    """oracle/philox_oracle.py (the independent statement of the device noise source) against the published Philox4x32-10 known-answer vectors
+    (Random123 kat_vectors: counter, key -> output)."""
+    from oracle import philox_oracle as po
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for c, k, exp in kat:
+        out = po.philox4x32_10(np.array([c], np.uint32), np.array([k], np.uint32))[0]
+        assert [int(v) for v in out] == list(exp)
+    z = po.randn(seed=7, stream_id=2, image_offset=3, B=4, per_image=3 * 16 * 16)
+    assert z.shape == (4, 768) and abs(float(z.mean())) < 0.05 and abs(float(z.std()) - 1.0) < 0.05
+    # keyed by the GLOBAL image index: image 1 of a batch at offset 3 is image 0 of a batch at offset 4
+    np.testing.assert_array_equal(z[1], po.randn(7, 2, 4, 1, 768)[0])
