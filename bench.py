@@ -176,9 +176,9 @@ def prox_roofline(eng, case, B, H, sf):
     ach = byts / (us * 1e-6) / 1e12
     tr = PMC_TRAFFIC.get(f"fftprox_sf{sf}_B{B}_{H}")        # committed PMC passes: sum of the apply kernels' fabric-side bytes per launch
     traffic = None if tr is None else int(sum(v["bytes_per_launch"] for v in tr["kernels"].values()))
-    wave = H == 256 and sf in (1, 2, 4)
-    kern = ("rfft4_rows + cfft4_cols(solve) + irfft4_rows (fft4.hip: one wave per 256-point transform, column-major half spectrum" if wave else
-            "rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip two-pass register kernels, row-major half spectrum" if H in (64, 512) and sf in (1, 2, 4) else "fft.hip c2c path (")
+    wave = H in (256, 512) and sf in (1, 2, 4)
+    kern = (f"rfft4_rows + cfft4_cols(solve) + irfft4_rows (fft4.hip: one wave per {H}-point transform, column-major half spectrum" if wave else
+            "rfft_rows + cfft_cols(solve) + irfft_rows (fft2.hip two-pass register kernels, row-major half spectrum" if H == 64 and sf in (1, 2, 4) else "fft.hip c2c path (")
     return {"bound": "hbm", "kernel": kern + ("" if sf == 1 else f", alias-grouped slots, sf = {sf}") + ")",
             "achieved": round(ach, 4), "peak": PEAK_HBM_TBS, "unit": "TB/s", "frac": round(ach / PEAK_HBM_TBS, 4),
             "us_per_apply": round(us, 2), "us_per_apply_event_pairs": round(us_ev, 2), "frac_event_pairs": round(byts / (us_ev * 1e-6) / 1e12 / PEAK_HBM_TBS, 4),
@@ -304,6 +304,11 @@ def main():
             c64 = {"y": rng.random((64, 3, H, H), dtype=np.float32), "gt": rng.random((64, 3, H, H), dtype=np.float32),
                    "k": np.repeat(synth.gaussian_psf(61, 3.0)[None, None], 64, 0)}
             prox["at_batch_64"] = {kk: v for kk, v in prox_roofline(eng, c64, 64, H, 1).items() if kk in ("achieved", "frac", "us_per_apply", "us_per_apply_event_pairs", "frac_event_pairs")}
+            # configs[4]'s data step alone (the "HBM-bound FFT prox stress"): 512 x 512, sf = 4, its per-GPU shard of 8 images; timing only
+            c5 = {"y": rng.random((8, 3, 128, 128), dtype=np.float32), "gt": rng.random((8, 3, 512, 512), dtype=np.float32),
+                  "k": np.repeat(synth.gaussian_psf(25, 2.0)[None, None], 8, 0)}
+            prox["c5_512_sf4_batch_8"] = {kk: v for kk, v in prox_roofline(eng, c5, 8, 512, 4).items()
+                                          if kk in ("kernel", "achieved", "frac", "us_per_apply", "us_per_apply_event_pairs", "frac_event_pairs", "algorithmic_bytes")}
 
     # ---- the fused data step of the loop (eps -> x0 prologue + FFT prox + re-noise/Philox epilogue: 3 launches per step)
     if extras and prox is not None and args.task == "deblur":

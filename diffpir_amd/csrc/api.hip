@@ -117,7 +117,7 @@ Status dpir_engine::fft2_table(int N, const float2** out) {
         double a = -2.0 * M_PI * (double)m / (double)N;
         tw[m] = make_float2((float)cos(a), (float)sin(a));
     }
-    if (N == 256) { tw.resize(WAVE_TW_OFFSET + WAVE_TW_COUNT); wave_tw_fill(tw.data(), tw.data() + WAVE_TW_OFFSET); }   // fft4_wave.h: per-lane constants
+    if (N == 256 || N == 512) { tw.resize(N + wave_tw_count(N)); wave_tw_fill(N, tw.data(), tw.data() + N); }   // fft4_wave.h: per-lane constants behind the table
     void* d = nullptr;
     DPIR_HIP(hipMalloc(&d, tw.size() * sizeof(float2)));
     DPIR_HIP(hipMemcpy(d, tw.data(), tw.size() * sizeof(float2), hipMemcpyHostToDevice));
@@ -416,8 +416,8 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
         DPIR_TRY(launch_psf_embed_real(s, k, kh, kw, psf, B, H, W));
         if (st->colmajor) {      // wave-per-transform kernels, column-major spectra (fft4.hip)
             const int NC = st->WP;
-            DPIR_TRY(launch_rfft4_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, NC, nullptr, 0, st->slot_col));
-            DPIR_TRY(launch_cfft4_cols(s, tw, st->FB, none, false, B, NC, e->cus));
+            DPIR_TRY(launch_rfft4_rows(s, tw, W, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, NC, nullptr, 0, st->slot_col));
+            DPIR_TRY(launch_cfft4_cols(s, tw, W, st->FB, none, false, B, NC));
             const float* ysrc4 = y;
             if (sf > 1) {
                 float* yup = nullptr;
@@ -425,10 +425,10 @@ static Status prox_precalc(dpir_engine* e, const float* y, const float* k, int k
                 DPIR_TRY(launch_upsample_real(s, y, sf, yup, B * 3, H / sf, W / sf));
                 ysrc4 = yup;
             }
-            DPIR_TRY(launch_rfft4_rows(s, tw, ysrc4, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, NC, nullptr, 0, st->slot_col));
-            DPIR_TRY(launch_cfft4_cols(s, tw, st->FBFy, none, false, B * 3, NC, e->cus));
+            DPIR_TRY(launch_rfft4_rows(s, tw, W, ysrc4, 1.f, 0.f, 1.f, nullptr, st->FBFy, B * 3, NC, nullptr, 0, st->slot_col));
+            DPIR_TRY(launch_cfft4_cols(s, tw, W, st->FBFy, none, false, B * 3, NC));
             DPIR_TRY(launch_precalc_finish2(s, st->FB, st->FBFy, st->F2B, B, (size_t)H * NC));
-            if (sf > 1) DPIR_TRY(launch_fold_f2b4(s, st->F2B, st->slot_col, NC, sf, st->invW, B));
+            if (sf > 1) DPIR_TRY(launch_fold_f2b4(s, st->F2B, st->slot_col, W, NC, sf, st->invW, B));
             return Status{};
         }
         DPIR_TRY(launch_rfft_rows(s, tw, psf, 1.f, 0.f, 1.f, nullptr, st->FB, B, W, nullptr, 0, st->slot_col));
@@ -565,9 +565,9 @@ static Status prox_passes(dpir_engine* e, const ProxState& st, const ProxPassArg
     const int P = st.B * 3, N = st.W;
     const RenoiseArgs ra{a.rn.xt, a.rn.sp, a.rn.lp, a.rn.n1, a.rn.n2, a.rn.stride, a.rn.with_n1};
     if (st.colmajor) {
-        DPIR_TRY(launch_rfft4_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, st.WP, a.fu.eps6, a.fu.out_ch, a.slot_col));
-        DPIR_TRY(launch_cfft4_cols(s, a.tw, a.hbuf, a.solve, true, P, st.WP, e->cus));
-        return launch_irfft4_rows(s, a.tw, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, st.WP, a.rn.xt ? &ra : nullptr, a.col_slot);
+        DPIR_TRY(launch_rfft4_rows(s, a.tw, st.W, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, st.WP, a.fu.eps6, a.fu.out_ch, a.slot_col));
+        DPIR_TRY(launch_cfft4_cols(s, a.tw, st.W, a.hbuf, a.solve, true, P, st.WP));
+        return launch_irfft4_rows(s, a.tw, st.W, a.hbuf, a.out, a.scale, a.oa, a.ob, a.blend_base, a.g, P, st.WP, a.rn.xt ? &ra : nullptr, a.col_slot);
     }
     DPIR_TRY(launch_rfft_rows(s, a.tw, a.x, a.pa, a.pb, a.pm, a.sp, a.hbuf, P, N, a.fu.eps6, a.fu.out_ch, a.slot_col));
     DPIR_TRY(launch_cfft_cols(s, a.tw, a.hbuf, a.solve, true, P, st.H));

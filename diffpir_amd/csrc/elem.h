@@ -101,17 +101,17 @@ Status launch_fold_f2b(hipStream_t s, const float* F2B, const int* slot_col, int
 Status launch_upsample_real(hipStream_t s, const float* y, int sf, float* out, int P, int h, int w);
 Status launch_cfft_cols(hipStream_t s, const float2* twN, float2* buf, const SolveArgs& a, bool solve, int P, int N);
 Status launch_precalc_finish2(hipStream_t s, const float2* FB, float2* FBFy, float* F2B, int B, size_t hw);
-// fft4.hip: one wave per 256-point transform, column-major half spectrum [plane][slot][row] (NC slots per plane); 256 x 256, sf 1 / 2 / 4
+// fft4.hip: one wave per N-point transform, column-major half spectrum [plane][slot][row] (NC slots per plane); N x N = 256 x 256 or 512 x 512, sf 1 / 2 / 4
 bool fft4_supported(int H, int W, int sf);
 int fft4_columns(int W, int sf);
 int fft4_row_pos(int u);      // position of row u inside a stored column
 void fft4_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>& col_slot);
-Status launch_rfft4_rows(hipStream_t s, const float2* tw, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
+Status launch_rfft4_rows(hipStream_t s, const float2* tw, int N, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
                          const float* eps6, int out_ch, const int* slot_col);
-Status launch_irfft4_rows(hipStream_t s, const float2* tw, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g, int P,
-                          int NC, const RenoiseArgs* ra, const int* col_slot);
-Status launch_cfft4_cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC, int cus);
-Status launch_fold_f2b4(hipStream_t s, const float* F2B, const int* slot_col, int NC, int sf, float* invW, int B);
+Status launch_irfft4_rows(hipStream_t s, const float2* tw, int N, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
+                          int P, int NC, const RenoiseArgs* ra, const int* col_slot);
+Status launch_cfft4_cols(hipStream_t s, const float2* tw, int N, float2* buf, const SolveArgs& a, bool solve, int P, int NC);
+Status launch_fold_f2b4(hipStream_t s, const float* F2B, const int* slot_col, int N, int NC, int sf, float* invW, int B);
 // the arguments of the three half-spectrum passes (rows forward -> columns with the solve -> rows inverse), whichever kernels run them
 struct RowsFuse { const float* eps6; int out_ch; };      // eps -> x0 prologue of the row pass (loop only)
 struct RenoiseFuse { float* xt; const StepDev* sp; const LoopDev* lp; const float* n1; const float* n2; size_t stride; int with_n1; };

@@ -80,7 +80,7 @@ struct ProxState {   // dpir_prox
     int B = 0, H = 0, W = 0, sf = 1;
     float2* FB = nullptr; float* F2B = nullptr; float2* FBFy = nullptr;
     bool half = false;     // true: half spectrum [.., H, WP] (fft2.hip; columns alias-grouped when sf > 1); false: bit-reversed full c2c (fft.hip)
-    bool colmajor = false; // half spectrum stored COLUMN-major [.., WP slots, H] for the wave-per-transform kernels (fft4.hip, 256 x 256)
+    bool colmajor = false; // half spectrum stored COLUMN-major [.., WP slots, H] for the wave-per-transform kernels (fft4.hip, 256 x 256 and 512 x 512)
     int WP = 0;            // stored row length (complex elements); colmajor: stored columns (slots) per plane
     float* invW = nullptr; // half && sf > 1: alias mean of F2B [B][H/sf][W/sf/2+1]
     const int* slot_col = nullptr; const int* col_slot = nullptr;     // half && sf > 1: device slot maps (engine-owned, fft2_map)
@@ -134,7 +134,7 @@ struct dpir_engine {
         graphs.clear();
     }
     unsigned long long* range_ctr = nullptr;     // f16x3 operand range guard (act.hip range_report), device
-    // how the half-spectrum data step is run (dpir_set_prox_launch): 1 = wave-per-transform kernels on a column-major spectrum (fft4.hip; 256 x 256, default),
+    // how the half-spectrum data step is run (dpir_set_prox_launch): 1 = wave-per-transform kernels on a column-major spectrum (fft4.hip; 256 x 256 and 512 x 512, default),
     // 0 = the two-pass register kernels (fft2.hip; every other size always).  cus: CU count of the device.
     int prox_mode = 1; int cus = 256;
     // conv7's fused hop (Conv6Emit) is an inter-workgroup wait; when it times out (the GPU is shared with other engines / processes) the

@@ -1,4 +1,4 @@
-// fft4: the half-spectrum FFT prox at N = 256 (utils/utils_sisr.py:9-19, 65-95; the headline deblurring / SR configurations) with ONE WAVE PER
+// fft4: the half-spectrum FFT prox at N = 256 and N = 512 (utils/utils_sisr.py:9-19, 65-95; the headline deblurring / SR configurations) with ONE WAVE PER
 // TRANSFORM (fft4_wave.h) and a COLUMN-MAJOR half spectrum [plane][slot][position].  Same mathematics as fft2.hip (row-pair packing, half spectrum,
 // closed-form solve between the column transforms), different mapping to the machine (bodies: fft4_body.h):
 //   * rows    : a workgroup = 8 waves = 8 pairs of real rows (row r with r + 64): float4 loads, wave-private LDS re-distribution, 256-point FFT in the wave,
@@ -19,49 +19,51 @@
 namespace dpir {
 
 // the three passes as one launch each (named kernels: they are what the rocprofv3 summaries under profiles/ list) (bodies: fft4_body.h)
+template <int N>
 __global__ __launch_bounds__(RTHREADS) void rfft4_rows_kernel(const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int NC,
                                                              const float2* tw, RowsFuse fu, const int* slot_col) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
-    rows4_body<false>(sm4, blockIdx.x, x, pa, pb, pm, sp, out, NC, tw, WaveTw{}, fu, slot_col);
+    rows4_body<N, false>(sm4, blockIdx.x, x, pa, pb, pm, sp, out, NC, tw, WaveTwN<N>{}, fu, slot_col);
 }
+template <int N>
 __global__ __launch_bounds__(RTHREADS) void irfft4_rows_kernel(const float2* in, float* out, float scale, float oa, float ob, const float* blend_base, float g,
                                                               int NC, const float2* tw, RenoiseFuse rn, const int* col_slot) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
-    irows4_body<false>(sm4, blockIdx.x, in, out, scale, oa, ob, blend_base, g, NC, tw, WaveTw{}, rn, col_slot, NoWait4{});
+    irows4_body<N, false>(sm4, blockIdx.x, in, out, scale, oa, ob, blend_base, g, NC, tw, WaveTwN<N>{}, rn, col_slot, NoWait4{});
 }
 // grid: P * ceil(NC / 4) workgroups of four waves: one item each
-template <int MODE, int SF>
+template <int MODE, int SF, int N>
 __global__ __launch_bounds__(THREADS4) void cfft4_cols_kernel(float2* buf, SolveArgs a, int NC, const float2* tw) {
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (NC + WAVES - 1) / WAVES;
     const int plane = blockIdx.x / groups;
-    const WaveTw w = wave_tw_load(tw, lane);
-    cols4_item_body<MODE, SF>(sm4 + wave * WLDS, sm4 + WAVES * WLDS, plane, blockIdx.x - plane * groups, wave, buf, a, NC, w, NoWait4{});
+    const WaveTwN<N> w = wave_tw_load<N>(tw, lane);
+    cols4_item_body<MODE, SF, N>(sm4 + wave * wlds(N), sm4 + WAVES * wlds(N), plane, blockIdx.x - plane * groups, wave, buf, a, NC, w, NoWait4{});
 }
 
 // invW[n, p, q] = mean over the sf x sf aliases of F2B (utils_sisr.py:71), column-major slots
-__global__ void fold_f2b4_kernel(const float* F2B, const int* slot_col, int NC, int sf, float* invW, size_t total) {
-    const int Hs = N4 / sf, QW = N4 / sf / 2 + 1;
+__global__ void fold_f2b4_kernel(const float* F2B, const int* slot_col, int N, int NC, int sf, float* invW, size_t total) {
+    const int Hs = N / sf, QW = N / sf / 2 + 1;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int q = (int)(i % QW);
         const int p = (int)((i / QW) % Hs);
         const size_t n = i / ((size_t)QW * Hs);
-        const float* pl = F2B + n * (size_t)NC * N4;
+        const float* pl = F2B + n * (size_t)NC * N;
         float acc = 0.f;
         for (int b = 0; b < sf; ++b) {
             const int slot = sf * q + b;
             const int cm = slot < NC ? slot_col[slot] : -1;
             if (cm < 0) continue;
             const int base_row = (cm >> 16) ? (Hs - p) % Hs : p;          // |FB|^2 is real: the mirrored alias is just the mirrored row
-            for (int a = 0; a < sf; ++a) acc += pl[(size_t)slot * N4 + pos4(base_row + a * Hs)];
+            for (int a = 0; a < sf; ++a) acc += pl[(size_t)slot * N + pos4(base_row + a * Hs)];
         }
         invW[i] = acc / (float)(sf * sf);
     }
 }
 
 int fft4_row_pos(int u) { return pos4(u); }
-bool fft4_supported(int H, int W, int sf) { return H == 256 && W == 256 && (sf == 1 || sf == 2 || sf == 4); }
+bool fft4_supported(int H, int W, int sf) { return H == W && (H == 256 || H == 512) && (sf == 1 || sf == 2 || sf == 4); }
 // stored columns (slots) per plane: W/2 + 1 for sf = 1, sf * (W/sf/2 + 1) alias-grouped slots otherwise
 int fft4_columns(int W, int sf) { return sf == 1 ? W / 2 + 1 : sf * (W / sf / 2 + 1); }
 // slot -> (column | mirrored << 16) or -1, column -> canonical slot: fft2's alias grouping without strip padding
@@ -79,44 +81,71 @@ void fft4_build_map(int N, int sf, std::vector<int>& slot_col, std::vector<int>&
         }
 }
 
-static size_t lds4(bool fold, int sf) { return ((size_t)WAVES * WLDS + (fold ? (size_t)WAVES * (N4 / sf) : 0)) * sizeof(float2); }
-static size_t lds4_rows(int NC) { return (size_t)RW * WLDS * sizeof(float2) + (size_t)NC * TST * sizeof(float4); }
+static size_t lds4(int N, bool fold, int sf) { return ((size_t)WAVES * wlds(N) + (fold ? (size_t)WAVES * (N / sf) : 0)) * sizeof(float2); }
+static size_t lds4_rows(int N, int NC) { return (size_t)RW * wlds(N) * sizeof(float2) + (size_t)NC * TST * sizeof(float4); }
 
-Status launch_rfft4_rows(hipStream_t s, const float2* tw, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
-                         const float* eps6, int out_ch, const int* slot_col) {
-    if (eps6 && !sp) return invalid("rfft4_rows: the fused x0 prologue reads its coefficients from the device step block");
-    const size_t pairs = (size_t)P * N4 / 2;            // a multiple of RW: no partial workgroup
-    hipLaunchKernelGGL(rfft4_rows_kernel, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(NC), s, x, pa, pb, pm, sp, out, NC, tw,
+// dynamic LDS above 64 KB (the 512-point row passes: 8 exchange tiles + the [slot][9] line tile = 74 KB) has to be allowed per kernel, once
+template <class K> static Status allow_lds(K kernel, size_t bytes) {
+    if (bytes > 64 * 1024) DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+    return Status{};
+}
+
+template <int N>
+static Status rows_fwd(hipStream_t s, const float2* tw, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
+                       const float* eps6, int out_ch, const int* slot_col) {
+    const size_t pairs = (size_t)P * N / 2;             // a multiple of RW: no partial workgroup
+    DPIR_TRY(allow_lds(rfft4_rows_kernel<N>, lds4_rows(N, NC)));
+    hipLaunchKernelGGL(rfft4_rows_kernel<N>, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(N, NC), s, x, pa, pb, pm, sp, out, NC, tw,
                        RowsFuse{eps6, out_ch}, slot_col);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
-Status launch_irfft4_rows(hipStream_t s, const float2* tw, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g, int P,
-                          int NC, const RenoiseArgs* ra, const int* col_slot) {
-    RenoiseFuse rn{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
-    if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
-    const size_t pairs = (size_t)P * N4 / 2;
-    hipLaunchKernelGGL(irfft4_rows_kernel, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(N4 / 2 + 1), s, in, out, scale, oa, ob, blend, g, NC,
+Status launch_rfft4_rows(hipStream_t s, const float2* tw, int N, const float* x, float pa, float pb, float pm, const StepDev* sp, float2* out, int P, int NC,
+                         const float* eps6, int out_ch, const int* slot_col) {
+    if (eps6 && !sp) return invalid("rfft4_rows: the fused x0 prologue reads its coefficients from the device step block");
+    if (N == 256) return rows_fwd<256>(s, tw, x, pa, pb, pm, sp, out, P, NC, eps6, out_ch, slot_col);
+    if (N == 512) return rows_fwd<512>(s, tw, x, pa, pb, pm, sp, out, P, NC, eps6, out_ch, slot_col);
+    return invalid("rfft4_rows: N must be 256 or 512");
+}
+template <int N>
+static Status rows_inv(hipStream_t s, const float2* tw, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g, int P,
+                       int NC, RenoiseFuse rn, const int* col_slot) {
+    const size_t pairs = (size_t)P * N / 2;
+    DPIR_TRY(allow_lds(irfft4_rows_kernel<N>, lds4_rows(N, N / 2 + 1)));
+    hipLaunchKernelGGL(irfft4_rows_kernel<N>, dim3((unsigned)(pairs / RW)), dim3(RTHREADS), lds4_rows(N, N / 2 + 1), s, in, out, scale, oa, ob, blend, g, NC,
                        tw, rn, col_slot);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
-Status launch_cfft4_cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC, int cus) {
-    (void)cus;
+Status launch_irfft4_rows(hipStream_t s, const float2* tw, int N, const float2* in, float* out, float scale, float oa, float ob, const float* blend, float g,
+                          int P, int NC, const RenoiseArgs* ra, const int* col_slot) {
+    RenoiseFuse rn{nullptr, nullptr, nullptr, nullptr, nullptr, 0, 0};
+    if (ra) rn = RenoiseFuse{ra->xt, ra->sp, ra->lp, ra->n1, ra->n2, ra->stride, ra->with_n1};
+    if (N == 256) return rows_inv<256>(s, tw, in, out, scale, oa, ob, blend, g, P, NC, rn, col_slot);
+    if (N == 512) return rows_inv<512>(s, tw, in, out, scale, oa, ob, blend, g, P, NC, rn, col_slot);
+    return invalid("irfft4_rows: N must be 256 or 512");
+}
+template <int N>
+static Status cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC) {
     const unsigned grid = (unsigned)(P * ((NC + WAVES - 1) / WAVES));
-    if (!solve) hipLaunchKernelGGL((cfft4_cols_kernel<0, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw);
-    else if (a.sf == 1) hipLaunchKernelGGL((cfft4_cols_kernel<2, 1>), dim3(grid), dim3(THREADS4), lds4(false, 1), s, buf, a, NC, tw);
+    if (!solve) hipLaunchKernelGGL((cfft4_cols_kernel<0, 1, N>), dim3(grid), dim3(THREADS4), lds4(N, false, 1), s, buf, a, NC, tw);
+    else if (a.sf == 1) hipLaunchKernelGGL((cfft4_cols_kernel<2, 1, N>), dim3(grid), dim3(THREADS4), lds4(N, false, 1), s, buf, a, NC, tw);
     else {
         if ((a.sf != 2 && a.sf != 4) || !a.invW || !a.slot_col || NC % a.sf) return invalid("cfft4_cols: bad sf > 1 arguments");
-        if (a.sf == 2) hipLaunchKernelGGL((cfft4_cols_kernel<3, 2>), dim3(grid), dim3(THREADS4), lds4(true, 2), s, buf, a, NC, tw);
-        else hipLaunchKernelGGL((cfft4_cols_kernel<3, 4>), dim3(grid), dim3(THREADS4), lds4(true, 4), s, buf, a, NC, tw);
+        if (a.sf == 2) hipLaunchKernelGGL((cfft4_cols_kernel<3, 2, N>), dim3(grid), dim3(THREADS4), lds4(N, true, 2), s, buf, a, NC, tw);
+        else hipLaunchKernelGGL((cfft4_cols_kernel<3, 4, N>), dim3(grid), dim3(THREADS4), lds4(N, true, 4), s, buf, a, NC, tw);
     }
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
-Status launch_fold_f2b4(hipStream_t s, const float* F2B, const int* slot_col, int NC, int sf, float* invW, int B) {
-    const size_t total = (size_t)B * (N4 / sf) * (N4 / sf / 2 + 1);
-    hipLaunchKernelGGL(fold_f2b4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F2B, slot_col, NC, sf, invW, total);
+Status launch_cfft4_cols(hipStream_t s, const float2* tw, int N, float2* buf, const SolveArgs& a, bool solve, int P, int NC) {
+    if (N == 256) return cols<256>(s, tw, buf, a, solve, P, NC);
+    if (N == 512) return cols<512>(s, tw, buf, a, solve, P, NC);
+    return invalid("cfft4_cols: N must be 256 or 512");
+}
+Status launch_fold_f2b4(hipStream_t s, const float* F2B, const int* slot_col, int N, int NC, int sf, float* invW, int B) {
+    const size_t total = (size_t)B * (N / sf) * (N / sf / 2 + 1);
+    hipLaunchKernelGGL(fold_f2b4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, F2B, slot_col, N, NC, sf, invW, total);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }

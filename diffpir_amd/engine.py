@@ -165,7 +165,7 @@ class Engine:
     precision = "f32"
 
     def set_prox_launch(self, mode):
-        """'wave' / 1: wave-per-transform kernels on a column-major spectrum (csrc/fft4.hip, 256 x 256; default); 'launches' / 0: the two-pass register
+        """'wave' / 1: wave-per-transform kernels on a column-major spectrum (csrc/fft4.hip, 256 x 256 and 512 x 512; default); 'launches' / 0: the two-pass register
         kernels (csrc/fft2.hip).  Takes effect at the next pre_calculate / loop call."""
         m = {"wave": 1, "launches": 0}.get(mode, mode)
         self._check(self.lib.dpir_set_prox_launch(self.h, int(m)))

@@ -153,8 +153,8 @@ int dpir_prox_fft_apply(dpir_engine* e, const dpir_prox* p, float* x0_dev, float
  * applies) -> device microseconds per apply, launch boundaries included.  x0 is overwritten n + 1 (+ n) times. */
 int dpir_prox_fft_apply_timed(dpir_engine* e, const dpir_prox* p, float* x0_dev, float tau, float guidance, int n, int use_graph, float* us_per_apply);
 /* Which kernels run the half-spectrum data_solution (utils/utils_sisr.py:65-75).  mode 1 (default; env DPIR_PROX_MODE=0 selects 0 at dpir_create), 256 x 256
- * only: one wave per 256-point transform (64 lanes x 4 points, permlane-swap 4 x 4 transposes, a wave-private LDS tile, no workgroup barrier inside a
- * transform) on a COLUMN-major half spectrum, csrc/fft4.hip.  mode 0, and every other size: the two-pass register kernels of csrc/fft2.hip (a thread holds
+ * and 512 x 512: one wave per 256- / 512-point transform (64 lanes x 4 / 8 points, permlane-swap / DPP register transposes, a wave-private LDS tile, no workgroup
+ * barrier inside a transform) on a COLUMN-major half spectrum, csrc/fft4.hip.  mode 0, and every other size: the two-pass register kernels of csrc/fft2.hip (a thread holds
  * 16 points) on the row-major padded spectrum.  Same mathematics, results within a few 1e-6 of each other.  A dpir_prox keeps the layout of the mode it
  * was created in (dpir_prox_read returns natural order either way).  Drops the captured step graphs. */
 int dpir_set_prox_launch(dpir_engine* e, int mode);

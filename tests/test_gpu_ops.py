@@ -74,15 +74,14 @@ def test_data_solution_full_size_vs_oracle_and_roundtrip(engine, H, W, sf):
     assert np.abs(out - z).max() < 1e-3
 
 
-@pytest.mark.parametrize("B,sf", [(5, 1), (3, 4), (3, 2), (16, 1)])
-def test_prox_wave_kernels_match_two_pass_kernels_and_oracle(B, sf):
-    """The two kernel families behind data_solution at 256 x 256 -- one wave per 256-point transform on a column-major spectrum (csrc/fft4.hip, the
+@pytest.mark.parametrize("B,sf,H", [(5, 1, 256), (3, 4, 256), (3, 2, 256), (16, 1, 256), (2, 1, 512), (3, 4, 512), (1, 2, 512)])
+def test_prox_wave_kernels_match_two_pass_kernels_and_oracle(B, sf, H):
+    """The two kernel families behind data_solution at 256 x 256 and 512 x 512 -- one wave per N-point transform on a column-major spectrum (csrc/fft4.hip, the
     default) and the two-pass register kernels (csrc/fft2.hip) -- on the same inputs: spectra read back in natural order, dpir_data_solution against the
     oracle (utils_sisr.py:65-75) in both, dpir_prox_fft_apply with and without the guidance blend against each other, repeated (a racy kernel would differ
     run to run), and the timed-apply entry."""
     import diffpir_amd
-    H = 256
-    rng = np.random.default_rng(100 * B + sf)
+    rng = np.random.default_rng(100 * B + sf + H)
     k = rng.random((B, 1, 25, 25)).astype(np.float32); k /= k.sum(axis=(2, 3), keepdims=True)
     y = rng.random((B, 3, H // sf, H // sf)).astype(np.float32)
     z = rng.random((B, 3, H, H)).astype(np.float32)
