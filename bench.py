@@ -5,9 +5,10 @@
         bench.py --gpus N --steps K --warmup W
 
 A "step" is ONE full restoration (100 NFE: init -> 100 x (UNet -> FFT prox -> re-noise) -> u8 output) of one batch of
-synthetic inputs per GPU.  Workload (--config): at N = 1 BASELINE configs[1] (c2: FFHQ topology, 256x256 Gaussian deblur, 61x61 PSF,
-B = 16); at N > 1 BASELINE's multi-GPU configs[3] (c4: FFHQ topology, motion deblur, B = 32 per GPU = 256 over 8 GPUs), or
---config c5 (512x512 class-conditional topology, x4 SISR, B = 8 per GPU = 64 over 8).  Inputs (y, k) are resident in HBM before
+synthetic inputs per GPU.  Workload (--config): BASELINE configs[1] PER GPU at every N (c2: FFHQ topology, 256x256 Gaussian deblur, 61x61 PSF,
+B = 16 per GPU) -- weak scaling with the per-GPU work fixed, so the N = 1, 2, 4, 8 values of one sweep are comparable; --config c4 is BASELINE's
+multi-GPU configs[3] (FFHQ topology, motion deblur, B = 32 per GPU = 256 over 8 GPUs) and --config c5 configs[4] (512x512 class-conditional topology, x4
+SISR, B = 8 per GPU = 64 over 8).  Inputs (y, k) are resident in HBM before
 the timed region; the loop is a replayed per-step hipGraph with device-side Philox noise; with N > 1 the batch is sharded by image
 (weak scaling, no data-path collective) and the u8 results are all-gathered over RCCL -- bound through the C ABI
 (dpir_allgather_results), engine-owned buffers, engine stream -- inside the timed region (diffpir_amd.dist, the function the
@@ -54,7 +55,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default=None, choices=["c2", "c4", "c5"],
-                    help="BASELINE workload: c2 = configs[1] (default at --gpus 1), c4 = configs[3] (default at --gpus > 1), c5 = configs[4]; "
+                    help="BASELINE workload per GPU: c2 = configs[1] (default at every --gpus: fixed per-GPU work), c4 = configs[3] (32 per GPU), c5 = configs[4]; "
                          "--batch / --size / --task / --model override single fields")
     ap.add_argument("--batch", type=int, default=None, help="images per GPU (weak scaling)")
     ap.add_argument("--nfe", type=int, default=100)
@@ -75,8 +76,8 @@ def parse():
     a = ap.parse_args()
     preset = {"c2": dict(model="ffhq", task="deblur", blur="gaussian", batch=16, size=256),
               "c4": dict(model="ffhq", task="deblur", blur="motion", batch=32, size=256),
-              "c5": dict(model="imagenet512", task="sr", blur="gaussian", batch=8, size=512)}[a.config or ("c2" if a.gpus == 1 else "c4")]
-    a.preset = a.config or ("c2" if a.gpus == 1 else "c4")
+              "c5": dict(model="imagenet512", task="sr", blur="gaussian", batch=8, size=512)}[a.config or "c2"]
+    a.preset = a.config or "c2"
     a.exact_preset = all(getattr(a, kk) in (None, v) for kk, v in preset.items()) and a.nfe == 100
     for kk, v in preset.items():
         if getattr(a, kk) is None:
@@ -469,7 +470,7 @@ def main():
     cpu = cpu_baseline_c1(weights, args.cpu_threads) if extras and not args.no_cpu_baseline else None
 
     if rank == 0:
-        names = {"c2": "configs[1]", "c4": f"configs[3] (batch {B} per GPU; BASELINE quotes 256 images over 8 GPUs)",
+        names = {"c2": "configs[1]" if world == 1 else f"configs[1] per GPU (weak scaling: batch {B} on each of {world} GPUs)", "c4": f"configs[3] (batch {B} per GPU; BASELINE quotes 256 images over 8 GPUs)",
                  "c5": f"configs[4] (batch {B} per GPU; BASELINE quotes 64 images over 8 GPUs)"}
         cfg_tag = (names[args.preset] if args.exact_preset else
                    "configs[2] topology/task (reduced batch or NFE)" if (args.model, args.task) == ("imagenet256", "sr") else

@@ -205,8 +205,8 @@ def test_rccl_two_ranks_two_devices(n):
 
 
 def test_bench_launch_line_two_ranks_two_devices_c4():
-    """The driver's N = 2 launch line on the default collective: BASELINE configs[3]'s per-GPU work (c4: FFHQ topology, motion PSF,
-    32 images per GPU), shortened to 6 NFE."""
+    """The N = 2 launch line on the default collective with `--config c4`: BASELINE configs[3]'s per-GPU work (FFHQ topology, motion PSF,
+    32 images per GPU), shortened to 6 NFE.  (Without --config the bench keeps configs[1]'s 16 images per GPU at every N.)"""
     _need_two_devices()
     import json
     import subprocess
