@@ -19,6 +19,12 @@ run ffhq_f16x3 pmc_mfma --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CY
 run ffhq_f16x3 pmc_FETCH_SIZE --kernel-trace --pmc FETCH_SIZE
 run ffhq_f16x3 pmc_WRITE_SIZE --kernel-trace --pmc WRITE_SIZE
 cp $GRAFT_REPO_ROOT/.commit_id $out/commit.txt 2>/dev/null || true
+# configs[4]'s data step alone: 512 x 512, sf = 4, 8 images
+export PROF_UNET=0 PROF_SIZE=512 PROF_B=8 PROF_SF=4
+run prox512 kernel_trace --kernel-trace
+run prox512 pmc_FETCH_SIZE --kernel-trace --pmc FETCH_SIZE
+run prox512 pmc_WRITE_SIZE --kernel-trace --pmc WRITE_SIZE
+export PROF_UNET=1 PROF_SIZE=256 PROF_B=16 PROF_SF=1
 [ "$2" = "headline" ] && exit 0
 export DIFFPIR_PRECISION=f32
 run ffhq_f32 kernel_trace --kernel-trace

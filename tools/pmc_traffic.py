@@ -58,6 +58,9 @@ out = {
     "fftprox_sf1_B16_256": klass(d, "ffhq_f16x3", r"rfft4_rows_kernel|cfft4_cols_kernel<2|irfft4_rows_kernel|rfft_rows_kernel|cfft_cols_kernel<16, 16, 2|cfft_cols_kernel<16, 2|irfft_rows_kernel", src),
     "fftprox_sf4_B32_256": klass(d, "in256_f16x3", r"rfft4_rows_kernel|cfft4_cols_kernel<3|irfft4_rows_kernel|rfft_rows_kernel|cfft_cols_kernel<16, 16, 3|cfft_cols_kernel<16, 3|irfft_rows_kernel", src),
 }
+if os.path.exists(os.path.join(d, "prox512_pmc_FETCH_SIZE.txt")):
+    out["fftprox_sf4_B8_512"] = klass(d, "prox512", r"rfft4_rows_kernel|cfft4_cols_kernel<3|irfft4_rows_kernel", src)
+    out["fftprox_sf4_B8_512"]["note"] = "configs[4]'s data step alone (tools/prof_forward.py with PROF_UNET=0 PROF_SIZE=512 PROF_B=8 PROF_SF=4)"
 out["ffhq_B16_256_f16x3"]["whole_forward"] = whole_forward(d, "ffhq_f16x3")
 out["imagenet256_B32_256_f16x3"]["whole_forward"] = whole_forward(d, "in256_f16x3")
 for k in ("fftprox_sf1_B16_256", "fftprox_sf4_B32_256"):
