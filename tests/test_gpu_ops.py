@@ -245,9 +245,9 @@ def test_device_philox_equals_the_independent_numpy_statement(engine):
         np.testing.assert_allclose(out.numpy(), ref, atol=4e-6, rtol=2e-6)
 
 
-@pytest.mark.parametrize("H", [64, 256])
+@pytest.mark.parametrize("H", [64, 256, 512])
 def test_device_noise_loop_equals_host_noise_loop_fed_with_the_same_philox_draws(H):
-    """dpir_run_loop in the mode the bench times (device Philox noise, drawn inside the fused inverse-row-FFT epilogue at 64^2 / 256^2) against the SAME loop in
+    """dpir_run_loop in the mode the bench times (device Philox noise, drawn inside the fused inverse-row-FFT epilogue at 64^2 / 256^2 / 512^2: fft2.hip and both sizes of fft4.hip) against the SAME loop in
     parity mode fed host tensors that oracle/philox_oracle.py generates with the loop's keying (stream 0 for x_T, 1 + 4 i / 2 + 4 i for step i's eta / zeta
     draws, global image index = image_offset + n): the perf-mode loop is the parity-mode loop with a different noise SOURCE and nothing else."""
     import diffpir_amd
