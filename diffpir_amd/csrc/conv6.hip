@@ -475,9 +475,13 @@ __global__ __launch_bounds__(256) void conv6_reduce_kernel(const float* partial,
     for (int i4 = lane; i4 < (HW >> 2); i4 += 64) {
         const size_t o = (size_t)plane * HW + (size_t)i4 * 4;
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < ksplit; ++k) {
-            const float4 t = *reinterpret_cast<const float4*>(partial + (size_t)k * total + o);
-            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        for (int k0 = 0; k0 < ksplit; k0 += 4) {       // four slabs requested together, added in slab order: same bits, a quarter of the round trips
+            float4 t[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) t[j] = *reinterpret_cast<const float4*>(partial + (size_t)min(k0 + j, ksplit - 1) * total + o);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k0 + j < ksplit) { v.x += t[j].x; v.y += t[j].y; v.z += t[j].z; v.w += t[j].w; }
         }
         v.x += bv; v.y += bv; v.z += bv; v.w += bv;
         if (res) {
