@@ -86,10 +86,13 @@ static size_t lds4_rows(int N, int NC) { return (size_t)RW * wlds(N) * sizeof(fl
 
 // dynamic LDS above 64 KB (the 512-point row passes: 8 exchange tiles + the [slot][9] line tile = 74 KB) has to be allowed per kernel, once
 template <class K> static Status allow_lds(K kernel, size_t bytes) {
-    static size_t allowed = 64 * 1024;          // per instantiation (= per kernel): raise the limit only when a launch needs more than was granted so far
-    if (bytes > allowed) {
+    static size_t allowed[64];                  // per instantiation (= per kernel) and device: raise the limit only when a launch needs more than was granted so far
+    if (bytes <= 64 * 1024) return Status{};
+    int dev = 0;
+    DPIR_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || bytes > allowed[dev]) {
         DPIR_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-        allowed = bytes;
+        if (dev >= 0 && dev < 64) allowed[dev] = bytes;
     }
     return Status{};
 }
