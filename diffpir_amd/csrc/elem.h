@@ -74,6 +74,7 @@ struct SolveArgs {
     const StepDev* sp;   // non-null: alpha = sp->tau
     // fft2.hip, sf > 1: mean of F2B over the aliases [B][H/sf][W/sf/2+1] and the slot map of the permuted half-spectrum layout
     const float* invW = nullptr; const int* slot_col = nullptr;
+    int images = 0;      // fft4.hip: set by the launcher (planes / 3)
 };
 Status launch_fft_cols_solve(hipStream_t s, const FftPlan& ph, float2* buf, const SolveArgs& a, int B, int H, int W);
 // inverse rows with real output: out = Re(ifft_row)*oa + ob, optionally blended: out = base + g*(val - base)

@@ -37,9 +37,23 @@ __global__ __launch_bounds__(THREADS4) void cfft4_cols_kernel(float2* buf, Solve
     extern __shared__ __attribute__((aligned(16))) float2 sm4[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int groups = (NC + WAVES - 1) / WAVES;
-    const int plane = blockIdx.x / groups;
+    int plane, item;
+    if (MODE >= 2) {
+        // The solve's FB / F2B (/ invW) belong to the IMAGE: the three colour planes of an (image, item) pair read the same 3-6 KB per wave.  Workgroup b runs on
+        // XCD b % 8 (own L2), so the pair's three workgroups are numbered 8 apart -- same XCD, dispatched back to back: the second and third hit that L2 instead of
+        // fetching the spectra again over the fabric (counter traffic of the batch-16 column pass: 57.2 -> see profiles).  Grid: 3 x (pairs rounded up to 8).
+        const int r = blockIdx.x & 7, t = blockIdx.x >> 3;
+        const int c = t % 3, pair = 8 * (t / 3) + r;
+        const int n = pair / groups;
+        if (n >= a.images) return;                                     // padding workgroups (whole workgroup: no barrier is left waiting)
+        item = pair - n * groups;
+        plane = 3 * n + c;
+    } else {
+        plane = blockIdx.x / groups;
+        item = blockIdx.x - plane * groups;
+    }
     const WaveTwN<N> w = wave_tw_load<N>(tw, lane);
-    cols4_item_body<MODE, SF, N>(sm4 + wave * wlds(N), sm4 + WAVES * wlds(N), plane, blockIdx.x - plane * groups, wave, buf, a, NC, w, NoWait4{});
+    cols4_item_body<MODE, SF, N>(sm4 + wave * wlds(N), sm4 + WAVES * wlds(N), plane, item, wave, buf, a, NC, w, NoWait4{});
 }
 
 // invW[n, p, q] = mean over the sf x sf aliases of F2B (utils_sisr.py:71), column-major slots
@@ -133,8 +147,15 @@ Status launch_irfft4_rows(hipStream_t s, const float2* tw, int N, const float2* 
     return invalid("irfft4_rows: N must be 256 or 512");
 }
 template <int N>
-static Status cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a, bool solve, int P, int NC) {
-    const unsigned grid = (unsigned)(P * ((NC + WAVES - 1) / WAVES));
+static Status cols(hipStream_t s, const float2* tw, float2* buf, const SolveArgs& a_in, bool solve, int P, int NC) {
+    const int groups = (NC + WAVES - 1) / WAVES;
+    unsigned grid = (unsigned)(P * groups);
+    SolveArgs a = a_in;
+    if (solve) {
+        if (P % 3) return invalid("cfft4_cols: the solve runs on the three colour planes of every image");
+        a.images = P / 3;
+        grid = 3u * (unsigned)(((size_t)(P / 3) * groups + 7) / 8 * 8);
+    }
     if (!solve) hipLaunchKernelGGL((cfft4_cols_kernel<0, 1, N>), dim3(grid), dim3(THREADS4), lds4(N, false, 1), s, buf, a, NC, tw);
     else if (a.sf == 1) hipLaunchKernelGGL((cfft4_cols_kernel<2, 1, N>), dim3(grid), dim3(THREADS4), lds4(N, false, 1), s, buf, a, NC, tw);
     else {
