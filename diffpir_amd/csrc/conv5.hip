@@ -15,6 +15,7 @@
 #include "common.h"
 #include "lds_dma.h"
 #include <vector>
+#include <stdlib.h>
 
 namespace dpir {
 
@@ -28,6 +29,7 @@ struct Conv5K {
     const char* w16; const float* bias; float* out; const float* res;
     int B, Cout, HW;
     int n_chunks, n_co_blocks;
+    int n_tiles, pair_xcd;            // 256-pixel tiles; co-blocks of a tile on one XCD (n_co_blocks > 1)
     long long total_px;
     float out_scale;
     const float* out_scale_dev;       // optional device scalar multiplied into out_scale (dgrad)
@@ -143,9 +145,20 @@ __global__ __launch_bounds__(256, 2) void conv5_mfma_kernel(Conv5K p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31;
     const int half = lane >> 5;
-    const int bid = blockIdx.x;             // plain order: measured faster than the XCD renumbering conv6.hip uses
-    const int co_blk = bid % p.n_co_blocks;
-    const int px0 = (bid / p.n_co_blocks) * 256;      // B * HW < 2^31 (launch_conv5): 32-bit pixel arithmetic
+    const int bid = blockIdx.x;             // plain tile order: measured faster than the XCD renumbering conv6.hip uses
+    int co_blk, tile;
+    if (p.pair_xcd) {
+        // several co-blocks read the SAME 256 pixels of X.  Workgroup b runs on XCD b % 8 (own L2): the co-blocks of a tile are numbered 8 apart -- one XCD,
+        // dispatched back to back -- so that the second ... n-th read of a row hits that L2 instead of going to HBM again (launch_conv5: DPIR_CONV5_PAIR)
+        const int t = bid >> 3;
+        co_blk = t % p.n_co_blocks;
+        tile = 8 * (t / p.n_co_blocks) + (bid & 7);
+        if (tile >= p.n_tiles) return;       // padding workgroups of the last group of eight (before any barrier)
+    } else {
+        co_blk = bid % p.n_co_blocks;
+        tile = bid / p.n_co_blocks;
+    }
+    const int px0 = tile * 256;             // B * HW < 2^31 (launch_conv5): 32-bit pixel arithmetic
     const int C = p.ca + p.cb;
     const int HW = p.HW;
     const int total_px = (int)p.total_px;
@@ -328,7 +341,10 @@ Status launch_conv5(hipStream_t s, const Conv5Args& a) {
     k.range_ctr = a.range_ctr;
     k.eprm = a.emit_prm; k.ehi = reinterpret_cast<_Float16*>(a.emit_hi); k.elo = reinterpret_cast<_Float16*>(a.emit_lo);
     k.eC8 = 2 * k.n_chunks;
-    const unsigned blocks = (unsigned)(((k.total_px + 255) / 256) * k.n_co_blocks);
+    k.n_tiles = (int)((k.total_px + 255) / 256);
+    static const bool pair_env = !(getenv("DPIR_CONV5_PAIR") && atoi(getenv("DPIR_CONV5_PAIR")) == 0);
+    k.pair_xcd = pair_env && k.n_co_blocks > 1 ? 1 : 0;
+    const unsigned blocks = k.pair_xcd ? (unsigned)((k.n_tiles + 7) / 8 * 8 * k.n_co_blocks) : (unsigned)(k.n_tiles * k.n_co_blocks);
     if (a.emit_hi) {
         if (a.prm || !a.emit_prm || (!a.x1 && !a.emit_lo)) return invalid("conv5: the plane-emitting variant takes the raw input and a GroupNorm table for the planes");
         if ((a.H * a.W) % 256 || C % 16 || C > kConv5EmitMaxC) return invalid("conv5: the plane-emitting variant needs H*W % 256 == 0 and a multiple of 16, at most 384, input channels");
