@@ -279,3 +279,36 @@ def test_device_noise_loop_equals_host_noise_loop_fed_with_the_same_philox_draws
         assert err < 1e-4
     finally:
         e.close()
+
+
+@pytest.mark.parametrize("B,H,sf", [(16, 256, 1), (64, 256, 1), (32, 256, 4), (8, 512, 4)])
+def test_prox_at_the_benched_batches_equals_single_image_runs_bitwise_and_is_affine(B, H, sf):
+    """Size-independent properties of data_solution at the batches the bench times (configs[1], its batch-64 line, configs[2], configs[4]'s shard), where the
+    oracle comparisons above run smaller batches: (i) the planes of a batch are independent problems, so image n of the batch must equal, BIT FOR BIT, the same image
+    solved alone (catches any batch-dependent indexing: the XCD pairing of the column pass and its padding workgroups, 32-bit offsets, the alias-grouped slots);
+    (ii) for fixed (y, k, alpha) the solution is affine in z: x(a z1 + (1 - a) z2) = a x(z1) + (1 - a) x(z2) (utils_sisr.py:65-75 is linear in FR)."""
+    import diffpir_amd
+    rng = np.random.default_rng(B + H + sf)
+    k = rng.random((B, 1, 25, 25)).astype(np.float32); k /= k.sum(axis=(2, 3), keepdims=True)
+    y = rng.random((B, 3, H // sf, H // sf)).astype(np.float32)
+    z1 = rng.random((B, 3, H, H)).astype(np.float32)
+    z2 = rng.random((B, 3, H, H)).astype(np.float32)
+    e = diffpir_amd.Engine(0)
+    try:
+        pre = sr.pre_calculate(e.to_device(y), e.to_device(k), sf)
+        x1 = sr.data_solution(e.to_device(z1), *pre, 0.05, sf).numpy()
+        x2 = sr.data_solution(e.to_device(z2), *pre, 0.05, sf).numpy()
+        a = np.float32(0.25)
+        xm = sr.data_solution(e.to_device(a * z1 + (1 - a) * z2), *pre, 0.05, sf).numpy()
+        lin = float(np.abs(xm - (a * x1 + (1 - a) * x2)).max())
+        scale = float(np.abs(x1).max())
+        print(f"data_solution B={B} {H}^2 sf={sf}: affine defect {lin:.2e} at output scale {scale:.2f}")
+        assert lin < 2e-4 * max(1.0, scale)
+        for n in sorted({0, B // 2, B - 1}):
+            p1 = sr.pre_calculate(e.to_device(y[n:n + 1]), e.to_device(k[n:n + 1]), sf)
+            for i, nm in ((0, "FB"), (2, "F2B"), (3, "FBFy")):
+                assert np.array_equal(p1[i].numpy(), pre[i].numpy()[n:n + 1]), (nm, n)
+            alone = sr.data_solution(e.to_device(z1[n:n + 1]), *p1, 0.05, sf).numpy()
+            assert np.array_equal(alone, x1[n:n + 1]), n
+    finally:
+        e.close()
