@@ -47,6 +47,8 @@ __device__ __forceinline__ float gn_G(float xv, float dAs, float4 m, float rstd,
 // pass 1: grid (B * 32, NS): workgroup (n, g, part) sums a contiguous share of the group's elements -> fp64 {sum G, sum G x_hat}
 // partials [B * 32][NS]; pass 2 folds the NS partials of its group in index order.  (One workgroup per group left 256 workgroups with
 // 262 144 elements each at 256^2: hundreds of microseconds per GroupNorm site.)
+constexpr int GN_BWD_Q = 4;      // float4 groups per thread of gn_bwd_apply_kernel
+
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p, int NS) {
     const int n = blockIdx.x >> 5, g = blockIdx.x & 31;
     const int part = blockIdx.y;
@@ -60,21 +62,32 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(GnBwdArgs p, int NS)
     double S1 = 0.0, S2 = 0.0;
     const bool vec = p.mode == 0 && (HWs & 3) == 0;
     if (vec) {
-        for (long long e4 = lo / 4 + threadIdx.x; e4 * 4 < hi; e4 += 256) {
-            const long long e = e4 * 4;
-            const int k = (int)(e / HWs), i = (int)(e - (long long)k * HWs);
-            const int c = g * cg + k;
-            const float* xp = c < p.x.ca ? p.x.a + ((size_t)n * p.x.ca + c) * HWs : p.x.b + ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
-            const float4 xv = *reinterpret_cast<const float4*>(xp + i);
-            const float4 dv = *reinterpret_cast<const float4*>(p.dA + ((size_t)n * C + c) * HWs + i);
-            const float4 m = p.prm[(size_t)n * C + c];
-            const float xs[4] = {xv.x, xv.y, xv.z, xv.w}, ds[4] = {dv.x, dv.y, dv.z, dv.w};
+        // four float4 groups of a thread are requested together (clamped index: no branch around the loads) and then accumulated in the order a
+        // one-at-a-time loop would visit them -- same sums, a quarter of the serialised memory round trips (the loop was latency-bound: 2.1 TB/s at 256^2)
+        const long long last4 = (hi - 1) / 4;
+        for (long long b4 = lo / 4 + threadIdx.x; b4 * 4 < hi; b4 += 1024) {
+            float4 xv[4], dv[4], mm[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                float xh;
-                const float G = gn_G(xs[u], ds[u], m, rstd, &xh);
-                S1 += (double)G;
-                S2 += (double)G * (double)xh;
+            for (int q = 0; q < 4; ++q) {
+                const long long e = (b4 + 256 * q <= last4 ? b4 + 256 * q : last4) * 4;
+                const int k = (int)(e / HWs), i = (int)(e - (long long)k * HWs);
+                const int c = g * cg + k;
+                const float* xp = c < p.x.ca ? p.x.a + ((size_t)n * p.x.ca + c) * HWs : p.x.b + ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
+                xv[q] = *reinterpret_cast<const float4*>(xp + i);
+                dv[q] = *reinterpret_cast<const float4*>(p.dA + ((size_t)n * C + c) * HWs + i);
+                mm[q] = p.prm[(size_t)n * C + c];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                if ((b4 + 256 * q) * 4 >= hi) continue;
+                const float xs[4] = {xv[q].x, xv[q].y, xv[q].z, xv[q].w}, ds[4] = {dv[q].x, dv[q].y, dv[q].z, dv[q].w};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    float xh;
+                    const float G = gn_G(xs[u], ds[u], mm[q], rstd, &xh);
+                    S1 += (double)G;
+                    S2 += (double)G * (double)xh;
+                }
             }
         }
     } else {
@@ -109,6 +122,29 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) 
     const int HWs = p.Hs * p.Ws;
     const int Ho = p.mode == 1 ? p.Hs * 2 : (p.mode == 2 ? p.Hs >> 1 : p.Hs), Wo = p.mode == 1 ? p.Ws * 2 : (p.mode == 2 ? p.Ws >> 1 : p.Ws);
     const int g = c / cg;
+    const bool in_a = c < p.x.ca;
+    const size_t base = in_a ? ((size_t)n * p.x.ca + c) * HWs : ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
+    const float* xp = (in_a ? p.x.a : p.x.b) + base;
+    float* dst = (in_a ? p.ga : p.gb) + base;
+    const int acc = in_a ? p.acc_a : p.acc_b;
+    const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
+    const bool vec = p.mode == 0 && (HWs & 3) == 0;
+    // GN_BWD_Q float4 groups per thread (4096 pixels per workgroup).  Everything that does not depend on the group's folded sums -- the pixels, their
+    // incoming gradients, the accumulation target -- is requested BEFORE the fold (it used to be a chain of four dependent round trips per 12 KB: 1.9 TB/s)
+    const int j0 = blockIdx.y * (256 * GN_BWD_Q) + threadIdx.x;         // float4 index of this thread's first group; the others are 256 apart
+    const int n4 = HWs >> 2;
+    float4 xv[GN_BWD_Q], dv[GN_BWD_Q], ov[GN_BWD_Q];
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < GN_BWD_Q; ++q) {
+            const int j = min(j0 + 256 * q, n4 - 1) * 4;
+            xv[q] = *reinterpret_cast<const float4*>(xp + j);
+            dv[q] = *reinterpret_cast<const float4*>(dp + j);
+            ov[q] = acc ? *reinterpret_cast<const float4*>(dst + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    }
+    const float rstd = p.stats[n * 32 + g].y;
+    const float4 m = p.prm[(size_t)n * C + c];
     __shared__ double2 part_sh[64];
     __shared__ float m_sh[2];
     if ((int)threadIdx.x < NS) part_sh[threadIdx.x] = p.sums[(size_t)(n * 32 + g) * NS + threadIdx.x];
@@ -121,34 +157,30 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) 
     }
     __syncthreads();
     const float m1 = m_sh[0], m2 = m_sh[1];
-    const float rstd = p.stats[n * 32 + g].y;
-    const float4 m = p.prm[(size_t)n * C + c];
-    const bool in_a = c < p.x.ca;
-    const size_t base = in_a ? ((size_t)n * p.x.ca + c) * HWs : ((size_t)n * p.x.cb + (c - p.x.ca)) * HWs;
-    const float* xp = (in_a ? p.x.a : p.x.b) + base;
-    float* dst = (in_a ? p.ga : p.gb) + base;
-    const int acc = in_a ? p.acc_a : p.acc_b;
-    const float* dp = p.dA + ((size_t)n * C + c) * ((size_t)Ho * Wo);
-    const int i0 = (blockIdx.y * 256 + threadIdx.x) * 4;
-    if (i0 >= HWs) return;
-    if (p.mode == 0 && (HWs & 3) == 0) {
-        const float4 xv = *reinterpret_cast<const float4*>(xp + i0);
-        const float4 dv = *reinterpret_cast<const float4*>(dp + i0);
-        float4 o = acc ? *reinterpret_cast<const float4*>(dst + i0) : make_float4(0.f, 0.f, 0.f, 0.f);
-        float xh, G;
-        G = gn_G(xv.x, dv.x, m, rstd, &xh); o.x += G - m1 - xh * m2;
-        G = gn_G(xv.y, dv.y, m, rstd, &xh); o.y += G - m1 - xh * m2;
-        G = gn_G(xv.z, dv.z, m, rstd, &xh); o.z += G - m1 - xh * m2;
-        G = gn_G(xv.w, dv.w, m, rstd, &xh); o.w += G - m1 - xh * m2;
-        *reinterpret_cast<float4*>(dst + i0) = o;
+    if (vec) {
+#pragma unroll
+        for (int q = 0; q < GN_BWD_Q; ++q) {
+            const int j = j0 + 256 * q;
+            if (j >= n4) break;
+            float4 o = ov[q];
+            float xh, G;
+            G = gn_G(xv[q].x, dv[q].x, m, rstd, &xh); o.x += G - m1 - xh * m2;
+            G = gn_G(xv[q].y, dv[q].y, m, rstd, &xh); o.y += G - m1 - xh * m2;
+            G = gn_G(xv[q].z, dv[q].z, m, rstd, &xh); o.z += G - m1 - xh * m2;
+            G = gn_G(xv[q].w, dv[q].w, m, rstd, &xh); o.w += G - m1 - xh * m2;
+            *reinterpret_cast<float4*>(dst + j * 4) = o;
+        }
         return;
     }
-    for (int i = i0; i < i0 + 4 && i < HWs; ++i) {
-        const int y = i / p.Ws, x = i - y * p.Ws;
-        float xh;
-        const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), m, rstd, &xh);
-        const float dx = G - m1 - xh * m2;
-        dst[i] = acc ? dst[i] + dx : dx;
+    for (int q = 0; q < GN_BWD_Q; ++q) {
+        const int i0 = (j0 + 256 * q) * 4;
+        for (int i = i0; i < i0 + 4 && i < HWs; ++i) {
+            const int y = i / p.Ws, x = i - y * p.Ws;
+            float xh;
+            const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), m, rstd, &xh);
+            const float dx = G - m1 - xh * m2;
+            dst[i] = acc ? dst[i] + dx : dx;
+        }
     }
 }
 
@@ -165,7 +197,7 @@ Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B) {
     if (a.mode == 2 && ((a.Hs | a.Ws) & 1)) return invalid("gn_bwd: pooled source must be even");
     const int NS = gn_bwd_parts(C, a.Hs, a.Ws);
     hipLaunchKernelGGL(gn_bwd_reduce_kernel, dim3(B * 32, NS), dim3(256), 0, s, a, NS);
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 1023) / 1024), dim3(256), 0, s, a, NS);
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3(B * C, (a.Hs * a.Ws + 1024 * GN_BWD_Q - 1) / (1024 * GN_BWD_Q)), dim3(256), 0, s, a, NS);
     DPIR_HIP(hipGetLastError());
     return Status{};
 }
@@ -208,9 +240,13 @@ __global__ __launch_bounds__(256) void absmax_kernel(const float* x, size_t tota
     float m = 0.f;
     const size_t n4 = total >> 2;                       // tensors here are [B, C, H, W] with H * W % 4 == 0 or tiny
     const float4* x4 = reinterpret_cast<const float4*>(x);
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
-        const float4 v = x4[i];
-        m = fmaxf(fmaxf(m, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += 4 * stride) {     // four requests in flight per thread (max is order-free)
+        float4 v[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const size_t j = i + q * stride; v[q] = x4[j < n4 ? j : n4 - 1]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) m = fmaxf(fmaxf(m, fmaxf(fabsf(v[q].x), fabsf(v[q].y))), fmaxf(fabsf(v[q].z), fabsf(v[q].w)));
     }
     for (size_t i = (n4 << 2) + (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[i]));
 #pragma unroll
