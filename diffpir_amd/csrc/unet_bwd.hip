@@ -24,6 +24,7 @@ struct Bwd {
     float* partial; size_t partial_cap; float* zeros;
     std::unordered_map<const float*, float*> gbuf;     // activation -> its gradient buffer
     std::unordered_map<const float*, bool> written;
+    const float* scaled = nullptr; bool scaled_f16 = false;      // the tensor the shared scale buffers currently describe
 
     Status grad_of(const float* act, size_t numel, float** out) {
         auto it = gbuf.find(act);
@@ -37,7 +38,9 @@ struct Bwd {
     bool take_acc(const float* act) { bool w = written[act]; written[act] = true; return w; }     // false: first writer assigns
 
     // dX [B, cin, H, W] = dgrad of cw applied to dY [B, cout, H, W]
-    Status dgrad(const ConvW& cw, const float* dY, float* dX, int H, int W) {
+    // reuse_scale: dY is the tensor the PREVIOUS dgrad call scaled (a ResBlock's dout feeds the skip projection's and conv2's dgrad back to back):
+    // its absmax / power-of-two scale / table are still in the shared buffers
+    Status dgrad(const ConvW& cw, const float* dY, float* dX, int H, int W, bool reuse_scale = false) {
         if (!cw.wT) return Status{DPIR_ERR_STATE, "gradient mode was not enabled before dpir_load_unet (dpir_enable_grad)"};
         static const bool f16_env = !(getenv("DPIR_DGRAD_F32") && atoi(getenv("DPIR_DGRAD_F32")) != 0);      // A/B switch (tools/, tests)
         const bool x1 = e->precision == 2;
@@ -52,10 +55,11 @@ struct Bwd {
             DPIR_TRY(ws.getT("bwd#scal", (size_t)4, &scal));
             DPIR_TRY(ws.getT("bwd#sprm", (size_t)B * 2048, &prm));
             if (C > 2048) return invalid("dgrad: more than 2048 channels");
-            {
+            if (!(reuse_scale && scaled == dY && scaled_f16)) {
                 ProfScope ps(&e->prof, PC_ELEM);
                 DPIR_TRY(launch_grad_scale(s, dY, (size_t)B * C * H * W, part, scal, prm, B * C));
             }
+            scaled = dY; scaled_f16 = true;
             if (use5) {
                 Conv5Args a5;
                 a5.src = CatSrc{dY, C, nullptr, 0}; a5.prm = prm; a5.w16 = cw.w16T; a5.w16_scale = cw.w16T_scale;
@@ -81,6 +85,7 @@ struct Bwd {
             ProfScope ps(&e->prof, PC_CONV3);
             return launch_conv6(s, a6);
         }
+        scaled = nullptr; scaled_f16 = false;
         ConvArgs a;
         a.src.a = dY; a.src.ca = cw.cout; a.src.Hs = H; a.src.Ws = W; a.src.mode = 0; a.src.prm = nullptr;
         a.w = cw.wT; a.bias = zeros; a.out = dX; a.res = nullptr;
@@ -127,7 +132,7 @@ struct Bwd {
         float *dA = nullptr, *gh1 = nullptr;
         DPIR_TRY(ws.getT("bwd#dA", (size_t)B * std::max(r.cin, r.cout) * t.Ho * t.Wo, &dA));
         DPIR_TRY(ws.getT("bwd#gh1", on, &gh1));
-        DPIR_TRY(dgrad(r.conv2, dout, dA, t.Ho, t.Wo));
+        DPIR_TRY(dgrad(r.conv2, dout, dA, t.Ho, t.Wo, t.sk != nullptr));
         DPIR_TRY(gn_bwd(CatSrc{t.h1, r.cout, nullptr, 0}, t.Ho, t.Wo, t.prm2, t.st2, dA, 0, gh1, false, nullptr, false));
         tap(r.name + "#h1", gh1, on);
         // in_layers: GroupNorm + SiLU [+ resampling] + conv1
