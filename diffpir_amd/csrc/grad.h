@@ -14,6 +14,9 @@ struct GnBwdArgs {
     const float* dA = nullptr; int mode = 0; int Hs = 0, Ws = 0;
     double2* sums = nullptr;
     float* ga = nullptr; float* gb = nullptr; int acc_a = 0, acc_b = 0;
+    // optional: a tensor shaped like x.a (mode 0, no concat) added into ga BEFORE dx -- the identity skip's gradient (unet.py:256), which used to be its own
+    // accum_adj pass over ga: ga = ((ga_old | 0) + extra) + dx, the same operations in the same order
+    const float* extra = nullptr;
 };
 int gn_bwd_parts(int C, int Hs, int Ws);
 Status launch_gn_bwd(hipStream_t s, const GnBwdArgs& a, int B);

@@ -133,6 +133,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) 
     // incoming gradients, the accumulation target -- is requested BEFORE the fold (it used to be a chain of four dependent round trips per 12 KB: 1.9 TB/s)
     const int j0 = blockIdx.y * (256 * GN_BWD_Q) + threadIdx.x;         // float4 index of this thread's first group; the others are 256 apart
     const int n4 = HWs >> 2;
+    const float* ex = (p.extra && in_a) ? p.extra + base : nullptr;
     float4 xv[GN_BWD_Q], dv[GN_BWD_Q], ov[GN_BWD_Q];
     if (vec) {
 #pragma unroll
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) 
             xv[q] = *reinterpret_cast<const float4*>(xp + j);
             dv[q] = *reinterpret_cast<const float4*>(dp + j);
             ov[q] = acc ? *reinterpret_cast<const float4*>(dst + j) : make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ex) { const float4 t = *reinterpret_cast<const float4*>(ex + j); ov[q].x += t.x; ov[q].y += t.y; ov[q].z += t.z; ov[q].w += t.w; }
         }
     }
     const float rstd = p.stats[n * 32 + g].y;
@@ -179,7 +181,9 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(GnBwdArgs p, int NS) 
             float xh;
             const float G = gn_G(xp[i], adj_read(dp, p.mode, y, x, p.Ws), m, rstd, &xh);
             const float dx = G - m1 - xh * m2;
-            dst[i] = acc ? dst[i] + dx : dx;
+            float o = acc ? dst[i] : 0.f;
+            if (ex) o += ex[i];
+            dst[i] = o + dx;
         }
     }
 }

@@ -95,8 +95,9 @@ struct Bwd {
         return launch_conv(s, a);
     }
     Status gn_bwd(const CatSrc& x, int Hs, int Ws, const float4* prm, const float2* st, const float* dA, int mode, float* ga, bool acc_a, float* gb,
-                  bool acc_b) {
+                  bool acc_b, const float* extra = nullptr) {
         GnBwdArgs g;
+        g.extra = extra;
         g.x = x; g.prm = prm; g.stats = st; g.dA = dA; g.mode = mode; g.Hs = Hs; g.Ws = Ws;
         DPIR_TRY(ws.getT("bwd#sums", (size_t)B * 32 * 64, &g.sums));
         g.ga = ga; g.gb = gb; g.acc_a = acc_a ? 1 : 0; g.acc_b = acc_b ? 1 : 0;
@@ -117,6 +118,7 @@ struct Bwd {
         DPIR_TRY(grad_of(t.in.a, (size_t)B * t.in.ca * in_px, &ga));
         if (t.in.b) DPIR_TRY(grad_of(t.in.b, (size_t)B * t.in.cb * in_px, &gb));
         // skip branch (unet.py:256 `self.skip_connection(x) + h`)
+        const float* fold_identity = nullptr;
         if (t.sk) {
             float* tmp = nullptr;
             DPIR_TRY(ws.getT("bwd#skiptmp", (size_t)B * r.cin * in_px, &tmp));
@@ -124,9 +126,11 @@ struct Bwd {
             ProfScope ps(&e->prof, PC_ELEM);
             DPIR_TRY(launch_accum_adj(s, tmp, r.cin, 0, ga, t.in.ca, 0, B, t.inH, t.inW, take_acc(t.in.a)));
             if (t.in.b) DPIR_TRY(launch_accum_adj(s, tmp, r.cin, t.in.ca, gb, t.in.cb, 0, B, t.inH, t.inW, take_acc(t.in.b)));
-        } else {
-            ProfScope ps(&e->prof, PC_ELEM);        // identity, or the up / down-sampled identity of the resampling blocks (x_upd)
+        } else if (r.mode != 0 || t.in.b || r.cout != t.in.ca) {
+            ProfScope ps(&e->prof, PC_ELEM);        // the up / down-sampled identity of the resampling blocks (x_upd)
             DPIR_TRY(launch_accum_adj(s, dout, r.cout, 0, ga, t.in.ca, r.mode, B, t.inH, t.inW, take_acc(t.in.a)));
+        } else {
+            fold_identity = dout;                    // plain identity: added inside the in_layers GroupNorm backward below (GnBwdArgs::extra), not as its own pass
         }
         // out_layers: GroupNorm + FiLM + SiLU + conv2
         float *dA = nullptr, *gh1 = nullptr;
@@ -138,7 +142,7 @@ struct Bwd {
         // in_layers: GroupNorm + SiLU [+ resampling] + conv1
         DPIR_TRY(dgrad(r.conv1, gh1, dA, t.Ho, t.Wo));
         const bool acc_a = take_acc(t.in.a), acc_b = t.in.b ? take_acc(t.in.b) : false;
-        DPIR_TRY(gn_bwd(t.in, t.inH, t.inW, t.prm1, t.st1, dA, r.mode, ga, acc_a, gb, acc_b));
+        DPIR_TRY(gn_bwd(t.in, t.inH, t.inW, t.prm1, t.st1, dA, r.mode, ga, acc_a, gb, acc_b, fold_identity));
         return Status{};
     }
 
